@@ -1,0 +1,203 @@
+"""Thin object layer over the C-ABI: Context (device + stream) and RegressionModel (L, alpha in HBM)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+class Context:
+    def __init__(self, device=0, stream=None):
+        self._lib = L.load()
+        h = C.c_void_p()
+        st = self._lib.gp_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h))
+        if st != L.GP_OK:
+            raise L.GpCoreError(st, "gp_ctx_create(device=%d) failed: no usable gfx950 GPU (no CPU fallback)" % device)
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            self._lib.gp_ctx_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def check(self, st, info=0):
+        if st == L.GP_OK:
+            return
+        msg = self._lib.gp_last_error(self.h).decode()
+        if st == L.GP_ENOTPD:
+            raise L.NotPositiveDefinite(st, msg, info)
+        if st == L.GP_EINVAL:
+            raise ValueError(msg)
+        if st == L.GP_ERANGE:
+            raise IndexError(msg)
+        raise L.GpCoreError(st, msg, info)
+
+    def sync(self):
+        self.check(self._lib.gp_ctx_sync(self.h))
+
+    # -- profiling --------------------------------------------------------------------------
+    def profile(self, which):
+        self.check(self._lib.gp_ctx_profile(self.h, which))
+
+    def profile_read(self, which):
+        n, ms, work = C.c_int64(), C.c_double(), C.c_double()
+        self.check(self._lib.gp_ctx_profile_read(self.h, which, C.byref(n), C.byref(ms), C.byref(work)))
+        return n.value, ms.value, work.value
+
+    def probe_mfma_f64(self):
+        v = C.c_double()
+        self.check(self._lib.gp_probe_mfma_f64(self.h, C.byref(v)))
+        return v.value
+
+    # -- raw device memory --------------------------------------------------------------------
+    def dev_alloc(self, nbytes):
+        p = C.c_void_p()
+        self.check(self._lib.gp_dev_alloc(self.h, nbytes, C.byref(p)))
+        return p
+
+    def dev_free(self, p):
+        self.check(self._lib.gp_dev_free(self.h, p))
+
+    def upload(self, host):
+        host = np.ascontiguousarray(host) if host.ndim == 1 else np.asfortranarray(host)
+        p = self.dev_alloc(host.nbytes)
+        self.check(self._lib.gp_dev_upload(self.h, p, host.ctypes.data_as(C.c_void_p), host.nbytes))
+        return p
+
+    def download(self, p, shape, dtype=np.float64):
+        out = np.empty(shape, dtype=dtype, order="F")
+        self.check(self._lib.gp_dev_download(self.h, out.ctypes.data_as(C.c_void_p), p, out.nbytes))
+        return out
+
+    # -- Gram / dense LA on host arrays -------------------------------------------------------
+    def gram_rbf(self, X, theta, full=True, out=None):
+        X, theta = L.f64(X), L.f64(theta)
+        n, d = X.shape
+        if theta.size != d + 2:
+            raise ValueError("%d does not equal to %d" % (theta.size, d + 2))
+        K = np.zeros((n, n), order="F") if out is None else out
+        self.check(self._lib.gp_gram_rbf(self.h, L.dptr(X), n, d, max(n, 1), L.dptr(theta), L.dptr(K), max(n, 1),
+                                         L.GP_FULL if full else L.GP_LOWER))
+        return K
+
+    def cross_gram_rbf(self, Xs, X, theta):
+        Xs, X, theta = L.f64(Xs), L.f64(X), L.f64(theta)
+        m, d = Xs.shape
+        n = X.shape[0]
+        if X.shape[1] != d or theta.size != d + 2:
+            raise ValueError("dimension mismatch")
+        Ks = np.zeros((m, n), order="F")
+        self.check(self._lib.gp_cross_gram_rbf(self.h, L.dptr(Xs), m, max(m, 1), L.dptr(X), n, max(n, 1), d, L.dptr(theta),
+                                               L.dptr(Ks), max(m, 1)))
+        return Ks
+
+    def potrf_lower(self, A):
+        A = np.array(A, dtype=np.float64, order="F", copy=True)
+        n = A.shape[0]
+        if A.shape[1] != n:
+            raise ValueError("matrix must be square")
+        info = C.c_int()
+        st = self._lib.gp_potrf_lower(self.h, L.dptr(A), n, max(n, 1), C.byref(info))
+        self.check(st, info.value)
+        return A
+
+    def trsm_lower(self, Lm, B, trans=False):
+        Lm = L.f64(Lm)
+        n = Lm.shape[0]
+        vec = np.ndim(B) == 1
+        Bm = np.array(np.reshape(B, (n, -1), order="F"), dtype=np.float64, order="F", copy=True)
+        self.check(self._lib.gp_trsm_lower(self.h, int(bool(trans)), L.dptr(Lm), n, max(n, 1), L.dptr(Bm), Bm.shape[1], max(n, 1)))
+        return Bm[:, 0].copy() if vec else Bm
+
+    def inv_lower(self, Lm):
+        Lm = L.f64(Lm)
+        n = Lm.shape[0]
+        out = np.zeros((n, n), order="F")
+        self.check(self._lib.gp_inv_lower(self.h, L.dptr(Lm), n, max(n, 1), L.dptr(out), max(n, 1)))
+        return out
+
+    def lml_grad_batched(self, X, y, thetas, nparams=None, sigma_noise=None):
+        X, y = L.f64(X), L.f64(y)
+        n, d = X.shape
+        thetas = np.ascontiguousarray(np.atleast_2d(thetas), dtype=np.float64)
+        B, P = thetas.shape
+        if P != d + 2 or y.size != n:
+            raise ValueError("dimension mismatch")
+        nparams = P if nparams is None else int(nparams)
+        lml = np.zeros(B)
+        grad = np.zeros((B, max(nparams, 1)))
+        info = np.zeros(B, dtype=np.int32)
+        sn = float("nan") if sigma_noise is None else float(sigma_noise)
+        self.check(self._lib.gp_lml_grad_rbf_batched(self.h, L.dptr(X), n, d, n, L.dptr(y), L.dptr(thetas), B, nparams, sn,
+                                                     L.dptr(lml), L.dptr(grad), info.ctypes.data_as(C.POINTER(C.c_int))))
+        return lml, grad[:, :nparams], info
+
+
+class RegressionModel:
+    """(L, alpha, LML) of GpPredictor.preComputeComponents, resident on the GPU."""
+
+    def __init__(self, ctx, X=None, y=None, theta=None, sigma_noise=None, gram=None):
+        self.ctx = ctx
+        lib = ctx._lib
+        h = C.c_void_p()
+        info = C.c_int()
+        sn = float("nan") if sigma_noise is None else float(sigma_noise)
+        y = L.f64(y)
+        if gram is not None:
+            K = L.f64(gram)
+            self.n, self.d = K.shape[0], 0
+            if y.size != self.n:
+                raise ValueError("Number of objects in training data matrix should be equal to targets vector length")
+            st = lib.gp_fit_from_gram(ctx.h, L.dptr(K), self.n, self.n, L.dptr(y), C.byref(h), C.byref(info))
+        else:
+            X, theta = L.f64(X), L.f64(theta)
+            self.n, self.d = X.shape
+            if y.size != self.n:
+                raise ValueError("Number of objects in training data matrix should be equal to targets vector length")
+            if theta.size != self.d + 2:
+                raise ValueError("%d does not equal to %d" % (theta.size, self.d + 2))
+            st = lib.gp_fit_rbf(ctx.h, L.dptr(X), self.n, self.d, self.n, L.dptr(y), L.dptr(theta), sn, C.byref(h), C.byref(info))
+        ctx.check(st, info.value)
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None) and getattr(self.ctx, "h", None):
+            self.ctx._lib.gp_model_destroy(self.h)
+        self.h = None
+
+    __del__ = close
+
+    def L(self):
+        out = np.zeros((self.n, self.n), order="F")
+        self.ctx.check(self.ctx._lib.gp_model_get(self.h, L.GP_GET_L, L.dptr(out), self.n))
+        return out
+
+    def alpha(self):
+        out = np.zeros(self.n)
+        self.ctx.check(self.ctx._lib.gp_model_get(self.h, L.GP_GET_ALPHA, L.dptr(out), self.n))
+        return out
+
+    def lml(self):
+        out = np.zeros(1)
+        self.ctx.check(self.ctx._lib.gp_model_get(self.h, L.GP_GET_LML, L.dptr(out), 1))
+        return float(out[0])
+
+    def predict(self, Xs, full_cov=False):
+        Xs = L.f64(Xs)
+        m = Xs.shape[0]
+        if Xs.shape[1] != self.d:
+            raise ValueError("test data dimension mismatch")
+        mean, var = np.zeros(m), np.zeros(m)
+        cov = np.zeros((m, m), order="F") if full_cov else None
+        self.ctx.check(self.ctx._lib.gp_predict(self.h, L.dptr(Xs), m, max(m, 1), L.dptr(mean), L.dptr(var),
+                                                L.dptr(cov) if full_cov else None, max(m, 1)))
+        return mean, var, cov

@@ -1,0 +1,666 @@
+// libgpcore.so -- C-ABI implementation (host orchestration over the HIP kernels).  gfx950 only.
+// Reference call stacks being replaced: SURVEY.md section 3; per-function citations in include/gpcore.h.
+#include "gpcore_internal.h"
+
+#include <algorithm>
+#include <new>
+
+// ------------------------------------------------------------------------------------------------
+// profiling: HIP events on the context's stream around one kernel class
+// ------------------------------------------------------------------------------------------------
+void gp_prof_begin(gp_ctx *ctx, int cls) {
+    if (ctx->prof_which != cls) return;
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return;
+    (void)hipEventRecord(e0, ctx->stream);
+    ctx->prof[cls].ev.push_back(e0);
+    ctx->prof[cls].ev.push_back(e1);
+}
+void gp_prof_end(gp_ctx *ctx, int cls, double work) {
+    if (ctx->prof_which != cls) return;
+    gp_prof_slot &p = ctx->prof[cls];
+    if (p.ev.size() < 2) return;
+    (void)hipEventRecord(p.ev.back(), ctx->stream);
+    p.launches += 1;
+    p.work += work;
+}
+
+namespace {
+
+struct ws_slot { void *p = nullptr; size_t bytes = 0; };
+enum { WS_VT = 0, WS_PARTIAL, WS_SUMSQ, WS_A, WS_B, WS_C, WS_D, WS_E, WS_COUNT };
+struct ctx_ext { ws_slot ws[WS_COUNT]; };
+
+// gp_ctx owns a ctx_ext through this side table (keeps the header struct POD-ish)
+ctx_ext *ext_of(gp_ctx *ctx);
+
+}  // namespace
+
+struct gp_ctx_full : gp_ctx { ctx_ext ext; };
+namespace {
+ctx_ext *ext_of(gp_ctx *ctx) { return &static_cast<gp_ctx_full *>(ctx)->ext; }
+
+gp_status ws_get(gp_ctx *ctx, int slot, size_t bytes, double **out) {
+    ws_slot &w = ext_of(ctx)->ws[slot];
+    if (w.bytes < bytes) {
+        if (w.p) { GP_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(w.p); w.p = nullptr; w.bytes = 0; }
+        size_t want = bytes + bytes / 8;
+        hipError_t e = hipMalloc(&w.p, want);
+        if (e != hipSuccess) { w.p = nullptr; GP_SET_ERR(ctx, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e)); return GP_ENOMEM; }
+        w.bytes = want;
+        GP_HIP(ctx, hipMemsetAsync(w.p, 0, want, ctx->stream));
+    }
+    *out = static_cast<double *>(w.p);
+    return GP_OK;
+}
+
+gp_status upload_2d(gp_ctx *ctx, double *dst, int ldd, const double *src, int lds, int rows, int cols) {
+    if (rows <= 0 || cols <= 0) return GP_OK;
+    GP_HIP(ctx, hipMemcpy2DAsync(dst, (size_t)ldd * 8, src, (size_t)lds * 8, (size_t)rows * 8, cols, hipMemcpyHostToDevice, ctx->stream));
+    return GP_OK;
+}
+gp_status download_2d(gp_ctx *ctx, double *dst, int ldd, const double *src, int lds, int rows, int cols) {
+    if (rows <= 0 || cols <= 0) return GP_OK;
+    GP_HIP(ctx, hipMemcpy2DAsync(dst, (size_t)ldd * 8, src, (size_t)lds * 8, (size_t)rows * 8, cols, hipMemcpyDeviceToHost, ctx->stream));
+    GP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GP_OK;
+}
+
+gp_status read_info(gp_ctx *ctx, int *info) {
+    int h = 0;
+    GP_HIP(ctx, hipMemcpyAsync(&h, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    GP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (info) *info = h;
+    return GP_OK;
+}
+
+double syrk_flops(int r, int K) {  // lower-triangle tiles incl. full diagonal tiles
+    double nb = r / (double)GP_NB;
+    return nb * (nb + 1) / 2.0 * 2.0 * GP_NB * GP_NB * (double)K;
+}
+
+// Blocked right-looking Cholesky of the padded np x np matrix A (lower), nb = 128:
+//   potrf_diag(Akk); A21 <- A21 Lkk^-T (trsm_panel); A22 -= A21 A21^T (MFMA syrk).
+// If t != nullptr (length np) the forward solve t <- L^-1 t rides along block by block.
+void chol_blocked(gp_ctx *ctx, double *A, int np, int lda, double *t) {
+    hipStream_t s = ctx->stream;
+    const int nblk = np / GP_NB;
+    for (int k = 0; k < nblk; ++k) {
+        double *Akk = A + (size_t)k * GP_NB + (size_t)k * GP_NB * lda;
+        gp_prof_begin(ctx, GP_PROF_POTRF_DIAG);
+        gpk_potrf_diag(s, Akk, lda, ctx->d_info, k * GP_NB);
+        gp_prof_end(ctx, GP_PROF_POTRF_DIAG, (double)GP_NB * GP_NB * GP_NB / 3.0);
+        if (t) gpk_trsv_diag(s, Akk, lda, t + (size_t)k * GP_NB, 0);
+        const int r = np - (k + 1) * GP_NB;
+        if (r <= 0) continue;
+        double *A21 = Akk + GP_NB;
+        gp_prof_begin(ctx, GP_PROF_TRSM);
+        gpk_trsm_panel(s, A21, r, lda, Akk, lda, nullptr);
+        gp_prof_end(ctx, GP_PROF_TRSM, (double)r * GP_NB * GP_NB);
+        if (t) gpk_gemv_panel_sub(s, A21, r, lda, t + (size_t)k * GP_NB, t + (size_t)(k + 1) * GP_NB);
+        double *A22 = A21 + (size_t)GP_NB * lda;
+        gp_prof_begin(ctx, GP_PROF_SYRK);
+        gpk_gemm_nt(s, r, r, GP_NB, -1.0, A21, lda, A21, lda, 1.0, A22, lda, 1);
+        gp_prof_end(ctx, GP_PROF_SYRK, syrk_flops(r, GP_NB));
+    }
+}
+
+// alpha <- L^-T t (block back substitution), in place on t
+void back_solve_vec(gp_ctx *ctx, const double *L, int np, int ldl, double *t) {
+    hipStream_t s = ctx->stream;
+    const int nblk = np / GP_NB;
+    for (int k = nblk - 1; k >= 0; --k) {
+        const double *Lkk = L + (size_t)k * GP_NB + (size_t)k * GP_NB * ldl;
+        const int r = np - (k + 1) * GP_NB;
+        if (r > 0) gpk_gemvT_panel_sub(s, Lkk + GP_NB, r, ldl, t + (size_t)(k + 1) * GP_NB, t + (size_t)k * GP_NB);
+        gpk_trsv_diag(s, Lkk, ldl, t + (size_t)k * GP_NB, 1);
+    }
+}
+
+// Vt (mp x np, ld mp) <- Vt * L^-T, block column by block column (forwardSolve(L, K*^T) transposed).
+// sumsq (length mp) accumulates row sums of squares of the result when non-null.
+void solve_rows_lower(gp_ctx *ctx, double *Vt, int mp, const double *L, int np, int ldl, double *sumsq) {
+    hipStream_t s = ctx->stream;
+    const int nblk = np / GP_NB;
+    for (int i = 0; i < nblk; ++i) {
+        double *Vi = Vt + (size_t)i * GP_NB * mp;
+        if (i > 0) {
+            gp_prof_begin(ctx, GP_PROF_GEMM);
+            gpk_gemm_nt(s, mp, GP_NB, i * GP_NB, -1.0, Vt, mp, L + (size_t)i * GP_NB, ldl, 1.0, Vi, mp, 0);
+            gp_prof_end(ctx, GP_PROF_GEMM, 2.0 * mp * GP_NB * (double)i * GP_NB);
+        }
+        gp_prof_begin(ctx, GP_PROF_TRSM);
+        gpk_trsm_panel(s, Vi, mp, mp, L + (size_t)i * GP_NB + (size_t)i * GP_NB * ldl, ldl, sumsq);
+        gp_prof_end(ctx, GP_PROF_TRSM, (double)mp * GP_NB * GP_NB);
+    }
+}
+
+// Vt (mp x np) <- Vt * U^-T with U (np x np) UPPER triangular: backward over block columns.
+void solve_rows_upper(gp_ctx *ctx, double *Vt, int mp, const double *U, int np, int ldu) {
+    hipStream_t s = ctx->stream;
+    const int nblk = np / GP_NB;
+    for (int i = nblk - 1; i >= 0; --i) {
+        double *Vi = Vt + (size_t)i * GP_NB * mp;
+        const int kr = (nblk - 1 - i) * GP_NB;
+        if (kr > 0) {
+            gp_prof_begin(ctx, GP_PROF_GEMM);
+            gpk_gemm_nt(s, mp, GP_NB, kr, -1.0, Vt + (size_t)(i + 1) * GP_NB * mp, mp,
+                        U + (size_t)i * GP_NB + (size_t)(i + 1) * GP_NB * ldu, ldu, 1.0, Vi, mp, 0);
+            gp_prof_end(ctx, GP_PROF_GEMM, 2.0 * mp * GP_NB * (double)kr);
+        }
+        gpk_trsm_panel_upper(s, Vi, mp, mp, U + (size_t)i * GP_NB + (size_t)i * GP_NB * ldu, ldu);
+    }
+}
+
+gp_status model_alloc(gp_ctx *ctx, int n, int d, bool has_x, gp_model **out) {
+    gp_model *m = new (std::nothrow) gp_model();
+    if (!m) return GP_ENOMEM;
+    m->ctx = ctx; m->n = n; m->d = d; m->np = gp_pad(n); m->has_x = has_x;
+    const size_t np = m->np;
+    hipError_t e = hipSuccess;
+    if (has_x) e = hipMalloc(&m->dX, sizeof(double) * (size_t)n * d);
+    if (e == hipSuccess) e = hipMalloc(&m->dy, sizeof(double) * np);
+    if (e == hipSuccess) e = hipMalloc(&m->dL, sizeof(double) * np * np);
+    if (e == hipSuccess) e = hipMalloc(&m->dalpha, sizeof(double) * np);
+    if (e == hipSuccess) e = hipMalloc(&m->dlml, sizeof(double) * 8);
+    if (e == hipSuccess) e = hipMemsetAsync(m->dL, 0, sizeof(double) * np * np, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(m->dy, 0, sizeof(double) * np, ctx->stream);
+    if (e != hipSuccess) {
+        GP_SET_ERR(ctx, "model allocation (n=%d) failed: %s", n, hipGetErrorString(e));
+        gp_model_destroy(m);
+        return GP_ENOMEM;
+    }
+    *out = m;
+    return GP_OK;
+}
+
+// factor the matrix already sitting in model->dL (lower), then alpha and LML
+void model_factor(gp_model *m) {
+    gp_ctx *ctx = m->ctx;
+    hipStream_t s = ctx->stream;
+    (void)hipMemsetAsync(ctx->d_info, 0, sizeof(int), s);
+    gpk_pad_identity(s, m->dL, m->n, m->np, m->np);
+    (void)hipMemcpyAsync(m->dalpha, m->dy, sizeof(double) * m->np, hipMemcpyDeviceToDevice, s);
+    chol_blocked(ctx, m->dL, m->np, m->np, m->dalpha);
+    back_solve_vec(ctx, m->dL, m->np, m->np, m->dalpha);
+    gpk_lml(s, m->dL, m->n, m->np, m->dy, m->dalpha, m->dlml);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *gp_version(void) { return "gpcore 0.1 (gfx950, fp64 MFMA)"; }
+
+gp_status gp_ctx_create(int device, void *stream, gp_ctx **out) {
+    if (!out) return GP_EINVAL;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return GP_EHIP;
+    gp_ctx_full *ctx = new (std::nothrow) gp_ctx_full();
+    if (!ctx) return GP_ENOMEM;
+    ctx->device = device;
+    hipError_t e = hipSetDevice(device);
+    hipDeviceProp_t prop;
+    if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
+    if (e == hipSuccess) {
+        ctx->num_cu = prop.multiProcessorCount;
+        if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) { delete ctx; return GP_EHIP; }  // gfx950 code objects only
+    }
+    if (e == hipSuccess) {
+        if (stream) { ctx->stream = static_cast<hipStream_t>(stream); ctx->own_stream = false; }
+        else { e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking); ctx->own_stream = true; }
+    }
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_a, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_b, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipMalloc(&ctx->d_scalars, sizeof(double) * 256);
+    if (e == hipSuccess) e = hipMalloc(&ctx->d_info, sizeof(int) * 4);
+    if (e == hipSuccess) e = hipMemset(ctx->d_info, 0, sizeof(int) * 4);
+    if (e == hipSuccess && gpk_init_kernels() != 0) e = hipErrorInvalidValue;
+    if (e != hipSuccess) { delete ctx; return GP_EHIP; }
+    *out = ctx;
+    return GP_OK;
+}
+
+void gp_ctx_destroy(gp_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (int c = 0; c < GP_PROF_NCLASSES; ++c)
+        for (hipEvent_t e : ctx->prof[c].ev) (void)hipEventDestroy(e);
+    ctx_ext *x = ext_of(ctx);
+    for (int i = 0; i < WS_COUNT; ++i) if (x->ws[i].p) (void)hipFree(x->ws[i].p);
+    if (ctx->d_scalars) (void)hipFree(ctx->d_scalars);
+    if (ctx->d_info) (void)hipFree(ctx->d_info);
+    if (ctx->ev_a) (void)hipEventDestroy(ctx->ev_a);
+    if (ctx->ev_b) (void)hipEventDestroy(ctx->ev_b);
+    if (ctx->side) (void)hipStreamDestroy(ctx->side);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete static_cast<gp_ctx_full *>(ctx);
+}
+
+gp_status gp_ctx_sync(gp_ctx *ctx) {
+    if (!ctx) return GP_EINVAL;
+    GP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GP_OK;
+}
+
+const char *gp_last_error(const gp_ctx *ctx) { return ctx ? ctx->err : "null context"; }
+
+gp_status gp_ctx_profile(gp_ctx *ctx, int which) {
+    if (!ctx || which < 0 || which >= GP_PROF_NCLASSES) return GP_EINVAL;
+    ctx->prof_which = which;
+    return GP_OK;
+}
+
+gp_status gp_ctx_profile_read(gp_ctx *ctx, int which, int64_t *launches, double *total_ms, double *work) {
+    if (!ctx || which <= 0 || which >= GP_PROF_NCLASSES) return GP_EINVAL;
+    GP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    gp_prof_slot &p = ctx->prof[which];
+    double ms = 0.0;
+    for (size_t i = 0; i + 1 < p.ev.size(); i += 2) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, p.ev[i], p.ev[i + 1]) == hipSuccess) ms += t;
+    }
+    for (hipEvent_t e : p.ev) (void)hipEventDestroy(e);
+    if (launches) *launches = p.launches;
+    if (total_ms) *total_ms = ms;
+    if (work) *work = p.work;
+    p.ev.clear(); p.launches = 0; p.work = 0.0;
+    return GP_OK;
+}
+
+gp_status gp_probe_mfma_f64(gp_ctx *ctx, double *tflops) {
+    if (!ctx || !tflops) return GP_EINVAL;
+    GP_HIP(ctx, hipSetDevice(ctx->device));
+    double v = gpk_probe_mfma(ctx->stream, ctx->num_cu);
+    if (v < 0) { GP_SET_ERR(ctx, "probe allocation failed"); return GP_ENOMEM; }
+    *tflops = v;
+    return GP_OK;
+}
+
+gp_status gp_dev_alloc(gp_ctx *ctx, size_t bytes, void **dptr) {
+    if (!ctx || !dptr) return GP_EINVAL;
+    GP_HIP(ctx, hipSetDevice(ctx->device));
+    hipError_t e = hipMalloc(dptr, bytes ? bytes : 8);
+    if (e != hipSuccess) { GP_SET_ERR(ctx, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e)); return GP_ENOMEM; }
+    return GP_OK;
+}
+gp_status gp_dev_free(gp_ctx *ctx, void *dptr) {
+    if (!ctx) return GP_EINVAL;
+    GP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (dptr) GP_HIP(ctx, hipFree(dptr));
+    return GP_OK;
+}
+gp_status gp_dev_upload(gp_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes) {
+    if (!ctx) return GP_EINVAL;
+    GP_HIP(ctx, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    GP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GP_OK;
+}
+gp_status gp_dev_download(gp_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes) {
+    if (!ctx) return GP_EINVAL;
+    GP_HIP(ctx, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    GP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GP_OK;
+}
+
+gp_status gp_hp_get_at_position(const double *theta, int d, int pos, double *out) {
+    if (!theta || !out || d < 0) return GP_EINVAL;
+    if (pos < 1 || pos > d + 2) return GP_ERANGE;
+    *out = theta[pos - 1];  // [sf, l_1..l_d, sn], 1-based
+    return GP_OK;
+}
+
+// ---- Gram ---------------------------------------------------------------------------------------
+gp_status gp_gram_rbf_dev(gp_ctx *ctx, const double *dX, int n, int d, int ldx, const double *theta, double *dK, int ldk, int uplo) {
+    if (!ctx) return GP_EINVAL;
+    GP_REQUIRE(ctx, dX && theta && dK, "null pointer");
+    GP_REQUIRE(ctx, n >= 0 && d >= 1 && d <= 64 && ldx >= n && ldk >= n, "bad dimensions (1 <= d <= 64)");
+    if (n == 0) return GP_OK;
+    gp_prof_begin(ctx, GP_PROF_GRAM);
+    gpk_gram_sym(ctx->stream, dX, n, d, ldx, theta, dK, ldk, uplo == GP_FULL, 0.0);
+    gp_prof_end(ctx, GP_PROF_GRAM, uplo == GP_FULL ? 8.0 * n * (double)n + 8.0 * n * d : 8.0 * n * (n + 1.0) / 2.0 + 8.0 * n * d);
+    return GP_OK;
+}
+
+gp_status gp_gram_rbf(gp_ctx *ctx, const double *X, int n, int d, int ldx, const double *theta, double *K, int ldk, int uplo) {
+    if (!ctx) return GP_EINVAL;
+    GP_REQUIRE(ctx, X && theta && K, "null pointer");
+    GP_REQUIRE(ctx, n >= 0 && d >= 1 && d <= 64 && ldx >= n && ldk >= n, "bad dimensions (1 <= d <= 64)");
+    if (n == 0) return GP_OK;
+    GP_HIP(ctx, hipSetDevice(ctx->device));
+    double *dX, *dK;
+    GP_TRY(ws_get(ctx, WS_A, sizeof(double) * (size_t)n * d, &dX));
+    GP_TRY(ws_get(ctx, WS_B, sizeof(double) * (size_t)n * n, &dK));
+    GP_TRY(upload_2d(ctx, dX, n, X, ldx, n, d));
+    if (uplo != GP_FULL) GP_TRY(upload_2d(ctx, dK, n, K, ldk, n, n));  // keep the caller's strict upper triangle
+    GP_TRY(gp_gram_rbf_dev(ctx, dX, n, d, n, theta, dK, n, uplo));
+    return download_2d(ctx, K, ldk, dK, n, n, n);
+}
+
+gp_status gp_cross_gram_rbf(gp_ctx *ctx, const double *Xs, int m, int ldxs, const double *X, int n, int ldx, int d, const double *theta, double *Ks, int ldks) {
+    if (!ctx) return GP_EINVAL;
+    GP_REQUIRE(ctx, Xs && X && theta && Ks, "null pointer");
+    GP_REQUIRE(ctx, m >= 0 && n >= 0 && d >= 1 && d <= 64 && ldxs >= m && ldx >= n && ldks >= m, "bad dimensions (1 <= d <= 64)");
+    if (m == 0 || n == 0) return GP_OK;
+    GP_HIP(ctx, hipSetDevice(ctx->device));
+    double *dXs, *dX, *dK;
+    GP_TRY(ws_get(ctx, WS_A, sizeof(double) * (size_t)m * d, &dXs));
+    GP_TRY(ws_get(ctx, WS_C, sizeof(double) * (size_t)n * d, &dX));
+    GP_TRY(ws_get(ctx, WS_B, sizeof(double) * (size_t)m * n, &dK));
+    GP_TRY(upload_2d(ctx, dXs, m, Xs, ldxs, m, d));
+    GP_TRY(upload_2d(ctx, dX, n, X, ldx, n, d));
+    gpk_gram_cross(ctx->stream, dXs, m, m, dX, n, n, d, theta, dK, m);
+    return download_2d(ctx, Ks, ldks, dK, m, m, n);
+}
+
+// ---- factorisation / solves ---------------------------------------------------------------------
+gp_status gp_potrf_lower(gp_ctx *ctx, double *A, int n, int lda, int *info) {
+    if (!ctx) return GP_EINVAL;
+    GP_REQUIRE(ctx, A && n >= 0 && lda >= n, "bad matrix");
+    if (info) *info = 0;
+    if (n == 0) return GP_OK;
+    GP_HIP(ctx, hipSetDevice(ctx->device));
+    const int np = gp_pad(n);
+    double *dA;
+    GP_TRY(ws_get(ctx, WS_B, sizeof(double) * (size_t)np * np, &dA));
+    GP_TRY(upload_2d(ctx, dA, np, A, lda, n, n));
+    gpk_pad_identity(ctx->stream, dA, n, np, np);
+    GP_HIP(ctx, hipMemsetAsync(ctx->d_info, 0, sizeof(int), ctx->stream));
+    chol_blocked(ctx, dA, np, np, nullptr);
+    gpk_zero_upper(ctx->stream, dA, n, np);
+    int h = 0;
+    GP_TRY(read_info(ctx, &h));
+    if (h) { if (info) *info = h; GP_SET_ERR(ctx, "matrix not positive definite at pivot %d", h); return GP_ENOTPD; }
+    return download_2d(ctx, A, lda, dA, np, n, n);
+}
+
+static gp_status trsm_impl(gp_ctx *ctx, int trans, const double *L, int n, int ldl, double *B, int nrhs, int ldb);
+
+gp_status gp_trsm_lower(gp_ctx *ctx, int trans, const double *L, int n, int ldl, double *B, int nrhs, int ldb) {
+    if (!ctx) return GP_EINVAL;
+    GP_REQUIRE(ctx, L && B && n >= 0 && nrhs >= 0 && ldl >= n && ldb >= n, "bad arguments");
+    if (n == 0 || nrhs == 0) return GP_OK;
+    GP_HIP(ctx, hipSetDevice(ctx->device));
+    return trsm_impl(ctx, trans, L, n, ldl, B, nrhs, ldb);
+}
+
+gp_status gp_inv_lower(gp_ctx *ctx, const double *L, int n, int ldl, double *Linv, int ldi) {
+    if (!ctx) return GP_EINVAL;
+    GP_REQUIRE(ctx, L && Linv && n >= 0 && ldl >= n && ldi >= n, "bad arguments");
+    for (int j = 0; j < n; ++j)
+        for (int i = 0; i < n; ++i) Linv[i + (size_t)j * ldi] = (i == j) ? 1.0 : 0.0;
+    return gp_trsm_lower(ctx, 0, L, n, ldl, Linv, n, ldi);
+}
+
+// ---- regression ---------------------------------------------------------------------------------
+gp_status gp_model_refit_dev(gp_model *m, const double *theta, double sigma_noise) {
+    if (!m) return GP_EINVAL;
+    gp_ctx *ctx = m->ctx;
+    GP_REQUIRE(ctx, m->has_x && theta, "model has no training inputs (built from a Gram matrix)");
+    m->theta.assign(theta, theta + m->d + 2);
+    m->sigma_noise = sigma_noise;
+    gp_prof_begin(ctx, GP_PROF_GRAM);
+    gpk_gram_sym(ctx->stream, m->dX, m->n, m->d, m->n, theta, m->dL, m->np, 0, std::isnan(sigma_noise) ? 0.0 : sigma_noise);
+    gp_prof_end(ctx, GP_PROF_GRAM, 8.0 * m->n * (m->n + 1.0) / 2.0 + 8.0 * m->n * m->d);
+    model_factor(m);
+    return GP_OK;
+}
+
+gp_status gp_model_status(gp_model *m, int *info) {
+    if (!m) return GP_EINVAL;
+    int h = 0;
+    GP_TRY(read_info(m->ctx, &h));
+    m->last_info = h;
+    if (info) *info = h;
+    if (h) { GP_SET_ERR(m->ctx, "matrix not positive definite at pivot %d", h); return GP_ENOTPD; }
+    return GP_OK;
+}
+
+gp_status gp_fit_rbf_dev(gp_ctx *ctx, const double *dX, int n, int d, int ldx, const double *dy, const double *theta, double sigma_noise, gp_model **out, int *info) {
+    if (!ctx || !out) return GP_EINVAL;
+    *out = nullptr;
+    GP_REQUIRE(ctx, dX && dy && theta, "null pointer");
+    GP_REQUIRE(ctx, n >= 1 && d >= 1 && d <= 64 && ldx >= n, "bad dimensions (n >= 1, 1 <= d <= 64)");
+    GP_HIP(ctx, hipSetDevice(ctx->device));
+    gp_model *m = nullptr;
+    GP_TRY(model_alloc(ctx, n, d, true, &m));
+    gpk_copy_2d(ctx->stream, m->dX, n, dX, ldx, n, d);
+    hipError_t e = hipMemcpyAsync(m->dy, dy, sizeof(double) * n, hipMemcpyDeviceToDevice, ctx->stream);
+    if (e != hipSuccess) { gp_model_destroy(m); GP_SET_ERR(ctx, "copy y: %s", hipGetErrorString(e)); return GP_EHIP; }
+    gp_status st = gp_model_refit_dev(m, theta, sigma_noise);
+    if (st == GP_OK) st = gp_model_status(m, info);
+    if (st != GP_OK) { gp_model_destroy(m); return st; }
+    *out = m;
+    return GP_OK;
+}
+
+gp_status gp_fit_rbf(gp_ctx *ctx, const double *X, int n, int d, int ldx, const double *y, const double *theta, double sigma_noise, gp_model **out, int *info) {
+    if (!ctx || !out) return GP_EINVAL;
+    *out = nullptr;
+    if (info) *info = 0;
+    GP_REQUIRE(ctx, X && y && theta, "null pointer");
+    GP_REQUIRE(ctx, n >= 1 && d >= 1 && d <= 64 && ldx >= n, "bad dimensions (n >= 1, 1 <= d <= 64)");
+    GP_HIP(ctx, hipSetDevice(ctx->device));
+    gp_model *m = nullptr;
+    GP_TRY(model_alloc(ctx, n, d, true, &m));
+    gp_status st = upload_2d(ctx, m->dX, n, X, ldx, n, d);
+    if (st == GP_OK) st = upload_2d(ctx, m->dy, n, y, n, n, 1);
+    if (st == GP_OK) st = gp_model_refit_dev(m, theta, sigma_noise);
+    if (st == GP_OK) st = gp_model_status(m, info);
+    if (st != GP_OK) { gp_model_destroy(m); return st; }
+    *out = m;
+    return GP_OK;
+}
+
+gp_status gp_fit_from_gram(gp_ctx *ctx, const double *K, int n, int ldk, const double *y, gp_model **out, int *info) {
+    if (!ctx || !out) return GP_EINVAL;
+    *out = nullptr;
+    if (info) *info = 0;
+    GP_REQUIRE(ctx, K && y && n >= 1 && ldk >= n, "bad arguments");
+    GP_HIP(ctx, hipSetDevice(ctx->device));
+    gp_model *m = nullptr;
+    GP_TRY(model_alloc(ctx, n, 0, false, &m));
+    gp_status st = upload_2d(ctx, m->dL, m->np, K, ldk, n, n);
+    if (st == GP_OK) st = upload_2d(ctx, m->dy, n, y, n, n, 1);
+    if (st == GP_OK) {
+        model_factor(m);
+        gpk_zero_upper(ctx->stream, m->dL, n, m->np);
+        st = gp_model_status(m, info);
+    }
+    if (st != GP_OK) { gp_model_destroy(m); return st; }
+    *out = m;
+    return GP_OK;
+}
+
+gp_status gp_model_get(gp_model *m, int what, double *out, int ld) {
+    if (!m || !out) return GP_EINVAL;
+    gp_ctx *ctx = m->ctx;
+    switch (what) {
+        case GP_GET_L:
+            GP_REQUIRE(ctx, ld >= m->n, "ld < n");
+            return download_2d(ctx, out, ld, m->dL, m->np, m->n, m->n);
+        case GP_GET_ALPHA:
+            return download_2d(ctx, out, m->n, m->dalpha, m->np, m->n, 1);
+        case GP_GET_LML:
+            return download_2d(ctx, out, 1, m->dlml, 1, 1, 1);
+        default:
+            GP_SET_ERR(ctx, "unknown selector %d", what);
+            return GP_EINVAL;
+    }
+}
+
+void gp_model_destroy(gp_model *m) {
+    if (!m) return;
+    if (m->ctx) { (void)hipSetDevice(m->ctx->device); (void)hipStreamSynchronize(m->ctx->stream); }
+    if (m->dX) (void)hipFree(m->dX);
+    if (m->dy) (void)hipFree(m->dy);
+    if (m->dL) (void)hipFree(m->dL);
+    if (m->dalpha) (void)hipFree(m->dalpha);
+    if (m->dwork) (void)hipFree(m->dwork);
+    if (m->dlml) (void)hipFree(m->dlml);
+    delete m;
+}
+
+// posterior at m test points already in HBM: mean, diagonal variance; Vt stays in the workspace
+static gp_status predict_core(gp_model *mdl, const double *dXs, int m, int ldxs, double *dmean, double *dvar, double **vt_out, int *mp_out) {
+    gp_ctx *ctx = mdl->ctx;
+    hipStream_t s = ctx->stream;
+    const int n = mdl->n, np = mdl->np, mp = gp_pad(m);
+    const int nchunk = 16;
+    double *Vt, *partial, *sumsq;
+    GP_TRY(ws_get(ctx, WS_VT, sizeof(double) * (size_t)mp * np, &Vt));
+    GP_TRY(ws_get(ctx, WS_PARTIAL, sizeof(double) * (size_t)nchunk * mp, &partial));
+    GP_TRY(ws_get(ctx, WS_SUMSQ, sizeof(double) * (size_t)mp, &sumsq));
+    if (np > n) gpk_fill(s, Vt + (size_t)n * mp, (size_t)mp * (np - n), 0.0);
+    if (mp > m) {  // pad rows: keep them finite (rows never mix, but NaNs would slow nothing and help nobody)
+        GP_HIP(ctx, hipMemset2DAsync(Vt + m, (size_t)mp * 8, 0, (size_t)(mp - m) * 8, n, s));
+    }
+    gp_prof_begin(ctx, GP_PROF_GRAM);
+    gpk_gram_cross(s, dXs, m, ldxs, mdl->dX, n, n, mdl->d, mdl->theta.data(), Vt, mp);
+    gp_prof_end(ctx, GP_PROF_GRAM, 8.0 * m * (double)n + 8.0 * (m + n) * mdl->d);
+    gpk_gemv_rows(s, Vt, m, n, mp, mdl->dalpha, dmean, partial, nchunk);
+    GP_HIP(ctx, hipMemsetAsync(sumsq, 0, sizeof(double) * mp, s));
+    solve_rows_lower(ctx, Vt, mp, mdl->dL, np, np, sumsq);
+    if (dvar) {
+        const double sf = mdl->theta[0], sn = mdl->theta[mdl->d + 1];
+        gpk_var_finish(s, dvar, sumsq, m, sf * sf + sn * sn);
+    }
+    if (vt_out) *vt_out = Vt;
+    if (mp_out) *mp_out = mp;
+    return GP_OK;
+}
+
+gp_status gp_predict_dev(gp_model *mdl, const double *dXs, int m, int ldxs, double *dmean, double *dvar) {
+    if (!mdl) return GP_EINVAL;
+    gp_ctx *ctx = mdl->ctx;
+    GP_REQUIRE(ctx, mdl->has_x, "model was built from a Gram matrix");
+    GP_REQUIRE(ctx, dXs && dmean && m >= 1 && ldxs >= m, "bad arguments");
+    return predict_core(mdl, dXs, m, ldxs, dmean, dvar, nullptr, nullptr);
+}
+
+gp_status gp_predict(gp_model *mdl, const double *Xs, int m, int ldxs, double *mean, double *var_diag, double *cov, int ldc) {
+    if (!mdl) return GP_EINVAL;
+    gp_ctx *ctx = mdl->ctx;
+    GP_REQUIRE(ctx, mdl->has_x, "model was built from a Gram matrix");
+    GP_REQUIRE(ctx, Xs && mean && m >= 0 && ldxs >= m && (!cov || ldc >= m), "bad arguments");
+    if (m == 0) return GP_OK;
+    GP_HIP(ctx, hipSetDevice(ctx->device));
+    const int d = mdl->d, mp = gp_pad(m);
+    double *dXs, *dout;
+    GP_TRY(ws_get(ctx, WS_A, sizeof(double) * (size_t)m * d, &dXs));
+    GP_TRY(ws_get(ctx, WS_C, sizeof(double) * (size_t)2 * mp, &dout));
+    GP_TRY(upload_2d(ctx, dXs, m, Xs, ldxs, m, d));
+    double *Vt = nullptr;
+    int mp2 = 0;
+    GP_TRY(predict_core(mdl, dXs, m, m, dout, dout + mp, &Vt, &mp2));
+    GP_TRY(download_2d(ctx, mean, m, dout, m, m, 1));
+    if (var_diag) GP_TRY(download_2d(ctx, var_diag, m, dout + mp, m, m, 1));
+    if (cov) {
+        // Sigma* = buildKernelMatrix(X*) - V^T V  (GpPredictor.scala:36): symmetric Gram of the test points
+        // (sn^2 on its diagonal) minus Vt Vt^T on the MFMA syrk, then mirrored on the host copy-out.
+        double *dC;
+        GP_TRY(ws_get(ctx, WS_D, sizeof(double) * (size_t)mp * mp, &dC));
+        gpk_gram_sym(ctx->stream, dXs, m, d, m, mdl->theta.data(), dC, mp, 1, 0.0);
+        gpk_pad_identity(ctx->stream, dC, m, mp, mp);
+        gp_prof_begin(ctx, GP_PROF_SYRK);
+        gpk_gemm_nt(ctx->stream, mp, mp, mdl->np, -1.0, Vt, mp, Vt, mp, 1.0, dC, mp, 1);
+        gp_prof_end(ctx, GP_PROF_SYRK, syrk_flops(mp, mdl->np));
+        GP_TRY(download_2d(ctx, cov, ldc, dC, mp, m, m));
+        for (int j = 0; j < m; ++j)
+            for (int i = 0; i < j; ++i) cov[i + (size_t)j * ldc] = cov[j + (size_t)i * ldc];
+    }
+    return GP_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// generic triangular solves with many right-hand sides, through the row-panel machinery:
+//   trans = 0:  L X = B    <=>  X^T = B^T L^-T      (forward over block columns)
+//   trans = 1:  L^T X = B  <=>  X^T = B^T L^-1      (backward; needs the NN product, done on L^T copy)
+// ------------------------------------------------------------------------------------------------
+
+static gp_status trsm_impl(gp_ctx *ctx, int trans, const double *L, int n, int ldl, double *B, int nrhs, int ldb) {
+    const int np = gp_pad(n), mp = gp_pad(nrhs);
+    double *dL, *dB, *dVt;
+    GP_TRY(ws_get(ctx, WS_B, sizeof(double) * (size_t)np * np, &dL));
+    GP_TRY(ws_get(ctx, WS_D, sizeof(double) * (size_t)np * mp, &dB));
+    GP_TRY(ws_get(ctx, WS_VT, sizeof(double) * (size_t)mp * np, &dVt));
+    hipStream_t s = ctx->stream;
+    GP_HIP(ctx, hipMemsetAsync(dL, 0, sizeof(double) * (size_t)np * np, s));
+    GP_HIP(ctx, hipMemsetAsync(dB, 0, sizeof(double) * (size_t)np * mp, s));
+    GP_TRY(upload_2d(ctx, dL, np, L, ldl, n, n));
+    gpk_zero_upper(s, dL, n, np);
+    gpk_pad_identity(s, dL, n, np, np);
+    GP_TRY(upload_2d(ctx, dB, np, B, ldb, n, nrhs));
+    gpk_transpose(s, dVt, mp, dB, np, np, mp);  // Vt = B^T  (mp x np)
+    if (!trans) {
+        solve_rows_lower(ctx, dVt, mp, dL, np, np, nullptr);
+    } else {
+        double *dU;
+        GP_TRY(ws_get(ctx, WS_E, sizeof(double) * (size_t)np * np, &dU));
+        gpk_transpose(s, dU, np, dL, np, np, np);  // U = L^T (upper), so X^T = B^T U^-T ... with U upper
+        solve_rows_upper(ctx, dVt, mp, dU, np, np);
+    }
+    gpk_transpose(s, dB, np, dVt, mp, mp, np);
+    return download_2d(ctx, B, ldb, dB, np, n, nrhs);
+}
+
+// ------------------------------------------------------------------------------------------------
+// LML + gradient at B hyper-parameter settings (GpPredictor.logLikelihoodWithDerivatives :60-80):
+//   fit -> (L, alpha, LML);  T = L^-T (rows of I solved against L);  Kinv = T T^T (MFMA syrk, k >= row block);
+//   fused traces over W = alpha alpha^T - Kinv.
+// ------------------------------------------------------------------------------------------------
+extern "C" gp_status gp_lml_grad_rbf_batched(gp_ctx *ctx, const double *X, int n, int d, int ldx, const double *y, const double *thetas,
+                                             int B, int nparams, double sigma_noise, double *lml, double *grad, int *info) {
+    if (!ctx) return GP_EINVAL;
+    GP_REQUIRE(ctx, X && y && thetas && lml, "null pointer");
+    GP_REQUIRE(ctx, n >= 1 && d >= 1 && d <= 64 && ldx >= n && B >= 0, "bad dimensions");
+    const int P = d + 2;
+    GP_REQUIRE(ctx, nparams >= 0 && nparams <= P && (nparams == 0 || grad), "0 <= nparams <= d+2");
+    if (B == 0) return GP_OK;
+    GP_HIP(ctx, hipSetDevice(ctx->device));
+    gp_model *m = nullptr;
+    GP_TRY(model_alloc(ctx, n, d, true, &m));
+    gp_status st = upload_2d(ctx, m->dX, n, X, ldx, n, d);
+    if (st == GP_OK) st = upload_2d(ctx, m->dy, n, y, n, n, 1);
+    const int np = m->np;
+    double *T = nullptr, *Kinv = nullptr, *partials = nullptr, *dres = nullptr;
+    if (st == GP_OK) st = ws_get(ctx, WS_VT, sizeof(double) * (size_t)np * np, &T);
+    if (st == GP_OK) st = ws_get(ctx, WS_D, sizeof(double) * (size_t)np * np, &Kinv);
+    if (st == GP_OK) st = ws_get(ctx, WS_PARTIAL, sizeof(double) * (size_t)gpk_lml_grad_partials_size(n, d), &partials);
+    if (st == GP_OK) st = ws_get(ctx, WS_C, sizeof(double) * (size_t)(P + 1), &dres);
+    hipStream_t s = ctx->stream;
+    std::vector<double> host(P + 1);
+    for (int b = 0; b < B && st == GP_OK; ++b) {
+        const double *theta = thetas + (size_t)b * P;
+        st = gp_model_refit_dev(m, theta, sigma_noise);
+        if (st != GP_OK) break;
+        if (nparams > 0) {
+            gpk_set_identity(s, T, np, np);
+            solve_rows_lower(ctx, T, np, m->dL, np, np, nullptr);       // T = L^-T (upper triangular)
+            gp_prof_begin(ctx, GP_PROF_SYRK);
+            gpk_gemm_nt(s, np, np, np, 1.0, T, np, T, np, 0.0, Kinv, np, 1, 1);  // Kinv = T T^T, lower
+            gp_prof_end(ctx, GP_PROF_SYRK, (double)np * np * np / 3.0);
+            gpk_lml_grad_traces(s, m->dX, n, d, n, theta, m->dalpha, Kinv, np, partials, dres + 1);
+        }
+        hipError_t e = hipMemcpyAsync(dres, m->dlml, sizeof(double), hipMemcpyDeviceToDevice, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(host.data(), dres, sizeof(double) * (P + 1), hipMemcpyDeviceToHost, s);
+        if (e != hipSuccess) { GP_SET_ERR(ctx, "copy results: %s", hipGetErrorString(e)); st = GP_EHIP; break; }
+        int h = 0;
+        st = read_info(ctx, &h);  // also syncs the stream
+        if (st != GP_OK) break;
+        if (info) info[b] = h;
+        lml[b] = h ? NAN : host[0];
+        for (int p = 0; p < nparams; ++p) grad[(size_t)b * nparams + p] = h ? NAN : host[1 + p];
+    }
+    gp_model_destroy(m);
+    return st;
+}
+
+// ------------------------------------------------------------------------------------------------
+// EP classification -- implemented in gpcore_ep.hip
+// ------------------------------------------------------------------------------------------------

@@ -1,0 +1,104 @@
+// Internal declarations shared by the HIP translation units of libgpcore.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <cmath>
+#include <vector>
+
+#include "../../include/gpcore.h"
+
+// All device matrices are padded to a multiple of GP_NB rows/cols.  A padded SPD matrix carries an
+// identity in the pad block, so chol([[K,0],[0,I]]) = [[L,0],[0,I]] and no kernel needs edge guards.
+constexpr int GP_NB = 128;   // Cholesky panel width == GEMM tile edge
+constexpr int GP_BK = 16;    // GEMM k-step
+static inline int gp_pad(int n) { return (n + GP_NB - 1) / GP_NB * GP_NB; }
+
+struct gp_prof_slot {
+    int64_t launches = 0;
+    double work = 0.0;
+    std::vector<hipEvent_t> ev;  // pairs (start, stop), resolved lazily at read time
+};
+
+struct gp_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipStream_t side = nullptr;      // look-ahead / overlap stream
+    bool own_stream = false;
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;
+    int prof_which = GP_PROF_OFF;
+    gp_prof_slot prof[GP_PROF_NCLASSES];
+    int num_cu = 256;
+    char err[512] = {0};
+    // scratch reused across calls
+    double *d_scalars = nullptr;  // small device scratch (256 doubles)
+    int *d_info = nullptr;        // device-side failing-pivot flag
+};
+
+struct gp_model {
+    gp_ctx *ctx = nullptr;
+    int n = 0, d = 0, np = 0;        // np = padded n
+    bool has_x = false;              // false for gp_fit_from_gram
+    double *dX = nullptr;            // n x d, ld = n
+    double *dy = nullptr;            // np
+    double *dL = nullptr;            // np x np, ld = np
+    double *dalpha = nullptr;        // np
+    double *dwork = nullptr;         // np x GP_NB panel workspace
+    double *dlml = nullptr;          // 1 double on device
+    std::vector<double> theta;       // d + 2
+    double sigma_noise = NAN;
+    int last_info = 0;
+};
+
+#define GP_SET_ERR(ctx, ...) do { if (ctx) snprintf((ctx)->err, sizeof((ctx)->err), __VA_ARGS__); } while (0)
+#define GP_HIP(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
+    GP_SET_ERR(ctx, "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); return GP_EHIP; } } while (0)
+#define GP_REQUIRE(ctx, cond, msg) do { if (!(cond)) { GP_SET_ERR(ctx, "invalid argument: %s", msg); return GP_EINVAL; } } while (0)
+#define GP_TRY(call) do { gp_status s_ = (call); if (s_ != GP_OK) return s_; } while (0)
+
+// ---- profiling helpers (gpcore_api.hip) ----
+void gp_prof_begin(gp_ctx *ctx, int cls);
+void gp_prof_end(gp_ctx *ctx, int cls, double work);
+
+// ---- kernel launchers (each asynchronous on `s`) ----
+// C[MxN] = beta*C + alpha * A[MxK] * B[NxK]^T, column-major; M,N multiples of 128, K multiple of 16.
+// lower != 0: M == N, only tiles on/below the diagonal are computed; on diagonal tiles only i >= j is stored.
+// ktri != 0: A(i,k) is zero for k < i (upper-triangular operand): each tile starts its k loop at its row block.
+void gpk_gemm_nt(hipStream_t s, int M, int N, int K, double alpha, const double *A, int lda, const double *B, int ldb,
+                 double beta, double *C, int ldc, int lower, int ktri = 0);
+// ARD-RBF Gram.  theta on host.  symmetric: Xb == Xa, noise on the diagonal, tiles bi >= bj only (mirrored if full).
+void gpk_gram_sym(hipStream_t s, const double *X, int n, int d, int ldx, const double *theta, double *K, int ldk, int full, double extra_diag);
+void gpk_gram_cross(hipStream_t s, const double *Xs, int m, int ldxs, const double *X, int n, int ldx, int d, const double *theta, double *Ks, int ldks);
+// set rows/cols [n, np) of the np x np matrix to identity (pad block) and zero the cross blocks.
+void gpk_pad_identity(hipStream_t s, double *A, int n, int np, int lda);
+void gpk_zero_upper(hipStream_t s, double *A, int n, int lda);
+void gpk_fill(hipStream_t s, double *p, size_t count, double v);
+// in-place Cholesky of the 128x128 diagonal block at A (ld lda); first failing pivot (1-based, + base) -> *d_info (if 0).
+void gpk_potrf_diag(hipStream_t s, double *A, int lda, int *d_info, int base);
+// X (M x 128, ldx) <- X * Lkk^{-T}  (rows solved independently by substitution); M multiple of 128.
+// if sumsq != nullptr: sumsq[p] += sum_c X(p,c)^2 accumulated in ascending column order.
+void gpk_trsm_panel(hipStream_t s, double *X, int M, int ldx, const double *Lkk, int ldl, double *sumsq);
+// X (M x 128) <- X * Ukk^{-T} with Ukk UPPER triangular (back substitution per row)
+void gpk_trsm_panel_upper(hipStream_t s, double *X, int M, int ldx, const double *Ukk, int ldu);
+void gpk_transpose(hipStream_t s, double *dst, int ldd, const double *src, int lds, int rows, int cols);
+void gpk_set_identity(hipStream_t s, double *A, int n, int lda);
+// LML-gradient traces (GpPredictor.scala:70-78 fused): out[0..d+1] = g_p for W = alpha alpha^T - Kinv (lower triangle of Kinv read)
+void gpk_lml_grad_traces(hipStream_t s, const double *X, int n, int d, int ldx, const double *theta, const double *alpha,
+                         const double *Kinv, int ldk, double *partials, double *out);
+int gpk_lml_grad_partials_size(int n, int d);
+// y (len M) -= A (M x 128, lda) * x (128)
+void gpk_gemv_panel_sub(hipStream_t s, const double *A, int M, int lda, const double *x, double *y);
+// y (len 128) -= A^T x: y[c] -= sum_r A(r,c) x[r], A is M x 128
+void gpk_gemvT_panel_sub(hipStream_t s, const double *A, int M, int lda, const double *x, double *y);
+// solve 128x128 diagonal block: trans=0: L t = b ; trans=1: L^T t = b ; in place on b (len 128)
+void gpk_trsv_diag(hipStream_t s, const double *Lkk, int ldl, double *b, int trans);
+// out[i] = sum_j Ks(i,j) * alpha[j], deterministic, j ascending per row chunk
+void gpk_gemv_rows(hipStream_t s, const double *Ks, int m, int n, int ldks, const double *alpha, double *out, double *partial, int nchunk);
+// lml = -0.5 y.alpha - sum log L_ii - n/2 log 2pi  (n real rows)
+void gpk_lml(hipStream_t s, const double *L, int n, int ldl, const double *y, const double *alpha, double *out);
+// var[i] = kss - sumsq[i]
+void gpk_var_finish(hipStream_t s, double *var, const double *sumsq, int m, double kss);
+void gpk_copy_2d(hipStream_t s, double *dst, int ldd, const double *src, int lds, int rows, int cols);
+double gpk_probe_mfma(hipStream_t s, int num_cu);
+int gpk_init_kernels();

@@ -1,0 +1,460 @@
+// Latency-bound pieces of the blocked fp64 Cholesky / triangular solves (gfx950):
+//   potrf_diag   : in-LDS Cholesky of one 128x128 diagonal block     (breeze.linalg.cholesky, GpPredictor.scala:120)
+//   trsm_panel   : X <- X * Lkk^-T, one thread per row, substitution  (MatrixUtils.solveTriangular, MatrixUtils.scala:123-133)
+//   trsv / gemv  : alpha = L^T \ (L \ y)                              (GpPredictor.scala:121-122)
+//   gemv_rows    : fMean = K* alpha, column-ascending accumulation     (GpPredictor.scala:33)
+//   lml          : -1/2 y.alpha - sum log L_ii - n/2 log 2 pi          (GpPredictor.scala:144-149)
+// The O(n^3) work lives in kernels_gemm.hip; these kernels sit on the critical path between GEMMs.
+#include "gpcore_internal.h"
+
+namespace {
+
+constexpr int NB = GP_NB;          // 128
+constexpr int LS = NB + 1;         // LDS column stride (doubles) -> conflict-free column sweeps
+
+// ---------------------------------------------------------------------------------------------
+// 128x128 Cholesky in LDS, right-looking, 256 threads.  On a non-positive pivot the first failing
+// 1-based global index is recorded in *info (if still 0) and the block is left partially factored.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void potrf_diag_kernel(double *__restrict__ A, int lda, int *info, int base) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double *a = sm;               // NB x LS
+    double *col = sm + NB * LS;   // NB
+    const int tid = threadIdx.x;
+    for (int e = tid; e < NB * NB; e += 256) {
+        int i = e & (NB - 1), j = e >> 7;
+        a[i + j * LS] = (i >= j) ? A[i + (size_t)j * lda] : 0.0;
+    }
+    const int i = tid & (NB - 1), half = tid >> 7;
+    bool failed = false;
+    for (int j = 0; j < NB; ++j) {
+        __syncthreads();
+        const double ajj = a[j + j * LS];
+        if (!(ajj > 0.0)) {
+            if (tid == 0) atomicCAS(info, 0, base + j + 1);
+            failed = true;
+            break;
+        }
+        const double djj = sqrt(ajj);
+        if (half == 0 && i >= j) {
+            double v = (i == j) ? djj : a[i + j * LS] / djj;
+            col[i] = v;
+            a[i + j * LS] = v;
+        }
+        __syncthreads();
+        const double li = col[i];
+        for (int c = j + 1 + half; c < NB; c += 2)
+            if (i >= c) a[i + c * LS] = fma(-li, col[c], a[i + c * LS]);
+    }
+    __syncthreads();
+    if (failed) return;
+    for (int e = tid; e < NB * NB; e += 256) {
+        int r = e & (NB - 1), c = e >> 7;
+        A[r + (size_t)c * lda] = (r >= c) ? a[r + c * LS] : 0.0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// X (M x 128) <- X * L^-T : each row p solves  L x_p^T = b_p^T  by forward substitution in 16-column
+// register chunks.  Earlier chunks of the same row are re-read from global (same thread wrote them),
+// L entries are wave-uniform (scalar loads).  sumsq[p] += sum_c x_pc^2 in ascending c.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void trsm_panel_kernel(double *__restrict__ X, int M, int ldx,
+                                                        const double *__restrict__ L, int ldl,
+                                                        double *__restrict__ sumsq) {
+    const int p = blockIdx.x * 64 + threadIdx.x;
+    if (p >= M) return;
+    double *xr = X + p;
+    double ss = 0.0;
+    for (int cb = 0; cb < NB; cb += 16) {
+        double acc[16];
+#pragma unroll
+        for (int cc = 0; cc < 16; ++cc) acc[cc] = xr[(size_t)(cb + cc) * ldx];
+        for (int k = 0; k < cb; ++k) {
+            const double xk = xr[(size_t)k * ldx];
+            const double *lk = L + cb + (size_t)k * ldl;
+#pragma unroll
+            for (int cc = 0; cc < 16; ++cc) acc[cc] = fma(-xk, lk[cc], acc[cc]);
+        }
+#pragma unroll
+        for (int cc = 0; cc < 16; ++cc) {
+            const double *lc = L + cb + (size_t)(cb + cc) * ldl;  // column cb+cc, rows cb..
+            const double x = acc[cc] / lc[cc];
+            acc[cc] = x;
+#pragma unroll
+            for (int c2 = cc + 1; c2 < 16; ++c2) acc[c2] = fma(-x, lc[c2], acc[c2]);
+        }
+#pragma unroll
+        for (int cc = 0; cc < 16; ++cc) {
+            xr[(size_t)(cb + cc) * ldx] = acc[cc];
+            ss = fma(acc[cc], acc[cc], ss);
+        }
+    }
+    if (sumsq) sumsq[p] += ss;
+}
+
+// y[p] -= sum_k A(p,k) x[k], A is M x 128
+__global__ __launch_bounds__(256) void gemv_panel_sub_kernel(const double *__restrict__ A, int M, int lda,
+                                                             const double *__restrict__ x, double *__restrict__ y) {
+    __shared__ double xs[NB];
+    if (threadIdx.x < NB) xs[threadIdx.x] = x[threadIdx.x];
+    __syncthreads();
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= M) return;
+    double acc = 0.0;
+#pragma unroll 8
+    for (int k = 0; k < NB; ++k) acc = fma(A[p + (size_t)k * lda], xs[k], acc);
+    y[p] -= acc;
+}
+
+// y[c] -= sum_r A(r,c) x[r], A is M x 128: one workgroup per column, fixed-order tree reduction
+__global__ __launch_bounds__(256) void gemvT_panel_sub_kernel(const double *__restrict__ A, int M, int lda,
+                                                              const double *__restrict__ x, double *__restrict__ y) {
+    __shared__ double red[256];
+    const int c = blockIdx.x;
+    double acc = 0.0;
+    for (int r = threadIdx.x; r < M; r += 256) acc = fma(A[r + (size_t)c * lda], x[r], acc);
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) y[c] -= red[0];
+}
+
+// 128x128 triangular solve with one right-hand side, in LDS.  trans = 0: L t = b; trans = 1: L^T t = b.
+__global__ __launch_bounds__(128) void trsv_diag_kernel(const double *__restrict__ L, int ldl, double *__restrict__ b, int trans) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double *a = sm;              // NB x LS, a[i + j*LS] = L(i,j)
+    double *v = sm + NB * LS;    // NB
+    const int tid = threadIdx.x;
+    for (int e = tid; e < NB * NB; e += 128) {
+        int i = e & (NB - 1), j = e >> 7;
+        a[i + j * LS] = L[i + (size_t)j * ldl];
+    }
+    v[tid] = b[tid];
+    __syncthreads();
+    if (!trans) {
+        for (int c = 0; c < NB; ++c) {
+            const double xc = v[c] / a[c + c * LS];
+            __syncthreads();
+            if (tid == c) v[c] = xc;
+            else if (tid > c) v[tid] = fma(-a[tid + c * LS], xc, v[tid]);
+            __syncthreads();
+        }
+    } else {
+        for (int c = NB - 1; c >= 0; --c) {
+            const double xc = v[c] / a[c + c * LS];
+            __syncthreads();
+            if (tid == c) v[c] = xc;
+            else if (tid < c) v[tid] = fma(-a[c + tid * LS], xc, v[tid]);
+            __syncthreads();
+        }
+    }
+    b[tid] = v[tid];
+}
+
+// partial[chunk][i] = sum_{j in chunk} Ks(i,j) alpha[j]  (j ascending); then out[i] = sum_chunk partial (ascending)
+__global__ __launch_bounds__(256) void gemv_rows_kernel(const double *__restrict__ Ks, int m, int n, int ldks,
+                                                        const double *__restrict__ alpha, double *__restrict__ partial,
+                                                        int nchunk) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int ch = blockIdx.y;
+    const int per = (n + nchunk - 1) / nchunk;
+    const int j0 = ch * per, j1 = min(n, j0 + per);
+    if (i >= m) return;
+    double acc = 0.0;
+#pragma unroll 8
+    for (int j = j0; j < j1; ++j) acc = fma(alpha[j], Ks[i + (size_t)j * ldks], acc);
+    partial[(size_t)ch * m + i] = acc;
+}
+__global__ void reduce_chunks_kernel(const double *__restrict__ partial, int m, int nchunk, double *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    double acc = 0.0;
+    for (int c = 0; c < nchunk; ++c) acc += partial[(size_t)c * m + i];
+    out[i] = acc;
+}
+
+__global__ __launch_bounds__(1024) void lml_kernel(const double *__restrict__ L, int n, int ldl, const double *__restrict__ y,
+                                                   const double *__restrict__ alpha, double *__restrict__ out) {
+    __shared__ double r1[1024], r2[1024];
+    double d = 0.0, lg = 0.0;
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        d = fma(y[i], alpha[i], d);
+        lg += log(L[i + (size_t)i * ldl]);
+    }
+    r1[threadIdx.x] = d;
+    r2[threadIdx.x] = lg;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if (threadIdx.x < s) { r1[threadIdx.x] += r1[threadIdx.x + s]; r2[threadIdx.x] += r2[threadIdx.x + s]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = -0.5 * r1[0] - r2[0] - 0.5 * (double)n * log(2.0 * M_PI);
+}
+
+__global__ void var_finish_kernel(double *__restrict__ var, const double *__restrict__ sumsq, int m, double kss) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) var[i] = kss - sumsq[i];
+}
+
+
+// X (M x 128) <- X * U^-T with U upper triangular: row p solves U x = b by BACK substitution
+// (columns 127 .. 0), in 16-column register chunks like trsm_panel_kernel.
+__global__ __launch_bounds__(64) void trsm_panel_upper_kernel(double *__restrict__ X, int M, int ldx,
+                                                              const double *__restrict__ U, int ldu) {
+    const int p = blockIdx.x * 64 + threadIdx.x;
+    if (p >= M) return;
+    double *xr = X + p;
+    for (int cb = NB - 16; cb >= 0; cb -= 16) {
+        double acc[16];
+#pragma unroll
+        for (int cc = 0; cc < 16; ++cc) acc[cc] = xr[(size_t)(cb + cc) * ldx];
+        for (int k = cb + 16; k < NB; ++k) {   // x_pc -= x_pk * U(c,k), k > c
+            const double xk = xr[(size_t)k * ldx];
+            const double *uk = U + cb + (size_t)k * ldu;
+#pragma unroll
+            for (int cc = 0; cc < 16; ++cc) acc[cc] = fma(-xk, uk[cc], acc[cc]);
+        }
+#pragma unroll
+        for (int cc = 15; cc >= 0; --cc) {
+            const double *uc = U + cb + (size_t)(cb + cc) * ldu;  // column cb+cc, rows cb..
+            const double x = acc[cc] / uc[cc];
+            acc[cc] = x;
+#pragma unroll
+            for (int c2 = 0; c2 < cc; ++c2) acc[c2] = fma(-x, uc[c2], acc[c2]);
+        }
+#pragma unroll
+        for (int cc = 0; cc < 16; ++cc) xr[(size_t)(cb + cc) * ldx] = acc[cc];
+    }
+}
+
+// dst (cols x rows) = src (rows x cols)^T, 64x64 LDS tiles, both sides coalesced
+__global__ __launch_bounds__(256) void transpose_kernel(double *__restrict__ dst, int ldd, const double *__restrict__ src, int lds,
+                                                        int rows, int cols) {
+    __shared__ double t[64][65];
+    const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int q = ty; q < 64; q += 4) {
+        int r = r0 + tx, c = c0 + q;
+        t[q][tx] = (r < rows && c < cols) ? src[r + (size_t)c * lds] : 0.0;
+    }
+    __syncthreads();
+    for (int q = ty; q < 64; q += 4) {
+        int c = c0 + tx, r = r0 + q;   // dst(c, r) = src(r, c) = t[c-c0][r-r0]
+        if (r < rows && c < cols) dst[c + (size_t)r * ldd] = t[tx][q];
+    }
+}
+
+__global__ void set_identity_kernel(double *A, int n, int lda) {
+    size_t total = (size_t)n * n;
+    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        int i = (int)(e % n), j = (int)(e / n);
+        A[i + (size_t)j * lda] = (i == j) ? 1.0 : 0.0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused LML-gradient traces (replaces P Gram-derivative builds + P dgemms, GpPredictor.scala:70-78):
+//   W = alpha alpha^T - Kinv ;  S_E = sum_ij W_ij E_ij ;  S_k = sum_ij W_ij E_ij (x_ik - x_jk)^2 ; T = tr W
+//   g_sf = sf S_E ; g_lk = sf^2 S_k / (2 l_k^3) ; g_sn = sn T          
+// One 64x64 tile of the lower triangle per workgroup (off-diagonal tiles count twice); E is
+// recomputed from X.  Per-workgroup partial sums are written out and reduced in a fixed order.
+// ---------------------------------------------------------------------------------------------
+constexpr int TR_T = 64, TR_DC = 8, TR_DMAX = 64;
+struct TraceParams { double inv_ls2[TR_DMAX]; };
+
+__device__ __forceinline__ void tile_lower_tr(int t, int &bi, int &bj) {
+    int b = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+    while (b * (b + 1) / 2 > t) --b;
+    while ((b + 1) * (b + 2) / 2 <= t) ++b;
+    bi = b;
+    bj = t - b * (b + 1) / 2;
+}
+
+__device__ __forceinline__ double block_sum_256(double v, double *red) {
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    double r = red[0];
+    __syncthreads();
+    return r;
+}
+
+__global__ __launch_bounds__(256) void lml_grad_trace_kernel(const double *__restrict__ X, int n, int d, int ldx, TraceParams prm,
+                                                             const double *__restrict__ alpha, const double *__restrict__ Kinv,
+                                                             int ldk, double *__restrict__ partials) {
+    __shared__ double xcs[TR_DC][TR_T];
+    __shared__ double red[256];
+    int bi, bj;
+    tile_lower_tr(blockIdx.x, bi, bj);
+    const int tid = threadIdx.x, ti = tid & 63, tq = tid >> 6;
+    const int gi = bi * TR_T + ti;
+    const bool diag_tile = (bi == bj);
+    const double wgt = diag_tile ? 1.0 : 2.0;
+    double r2[16], we[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) r2[q] = 0.0;
+    // pass 1: squared distances
+    for (int kc = 0; kc < d; kc += TR_DC) {
+        __syncthreads();
+        for (int e = tid; e < TR_DC * TR_T; e += 256) {
+            int kk = e >> 6, jj = e & 63, gj = bj * TR_T + jj;
+            xcs[kk][jj] = (gj < n && kc + kk < d) ? X[gj + (size_t)(kc + kk) * ldx] : 0.0;
+        }
+        double xi[TR_DC];
+#pragma unroll
+        for (int kk = 0; kk < TR_DC; ++kk) xi[kk] = (gi < n && kc + kk < d) ? X[gi + (size_t)(kc + kk) * ldx] : 0.0;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int jj = tq + 4 * q;
+#pragma unroll
+            for (int kk = 0; kk < TR_DC; ++kk) {
+                double diff = xi[kk] - xcs[kk][jj];
+                double inv = (kc + kk < d) ? prm.inv_ls2[kc + kk] : 0.0;
+                r2[q] = fma(diff * inv, diff, r2[q]);
+            }
+        }
+    }
+    // weights W_ij * E_ij (zero outside the matrix); trace of W from the diagonal tiles
+    const double ai = (gi < n) ? alpha[gi] : 0.0;
+    double sE = 0.0, tr = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int jj = tq + 4 * q, gj = bj * TR_T + jj;
+        double w = 0.0;
+        if (gi < n && gj < n) {
+            const int hi = gi > gj ? gi : gj, lo = gi > gj ? gj : gi;
+            w = ai * alpha[gj] - Kinv[hi + (size_t)lo * ldk];
+            if (gi == gj) tr += w;
+        }
+        we[q] = wgt * w * exp(-0.5 * r2[q]);
+        sE += we[q];
+    }
+    double *out = partials + (size_t)blockIdx.x * (d + 2);
+    double v = block_sum_256(sE, red);
+    if (tid == 0) out[0] = v;
+    v = block_sum_256(tr, red);
+    if (tid == 0) out[d + 1] = v;
+    // pass 2: per-feature weighted squared differences
+    for (int kc = 0; kc < d; kc += TR_DC) {
+        __syncthreads();
+        for (int e = tid; e < TR_DC * TR_T; e += 256) {
+            int kk = e >> 6, jj = e & 63, gj = bj * TR_T + jj;
+            xcs[kk][jj] = (gj < n && kc + kk < d) ? X[gj + (size_t)(kc + kk) * ldx] : 0.0;
+        }
+        double xi[TR_DC], sk[TR_DC];
+#pragma unroll
+        for (int kk = 0; kk < TR_DC; ++kk) {
+            xi[kk] = (gi < n && kc + kk < d) ? X[gi + (size_t)(kc + kk) * ldx] : 0.0;
+            sk[kk] = 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int jj = tq + 4 * q;
+#pragma unroll
+            for (int kk = 0; kk < TR_DC; ++kk) {
+                double diff = xi[kk] - xcs[kk][jj];
+                sk[kk] = fma(we[q], diff * diff, sk[kk]);
+            }
+        }
+#pragma unroll
+        for (int kk = 0; kk < TR_DC; ++kk) {
+            double tot = block_sum_256(sk[kk], red);
+            if (tid == 0 && kc + kk < d) out[1 + kc + kk] = tot;
+        }
+    }
+}
+
+struct TraceScale { double s[TR_DMAX + 2]; };
+__global__ __launch_bounds__(256) void lml_grad_reduce_kernel(const double *__restrict__ partials, int nblocks, int P, TraceScale sc,
+                                                              double *__restrict__ out) {
+    __shared__ double red[256];
+    const int p = blockIdx.x;
+    double acc = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += 256) acc += partials[(size_t)b * P + p];
+    double tot = block_sum_256(acc, red);
+    if (threadIdx.x == 0) out[p] = sc.s[p] * tot;
+}
+
+}  // namespace
+
+void gpk_trsm_panel_upper(hipStream_t s, double *X, int M, int ldx, const double *Ukk, int ldu) {
+    if (M <= 0) return;
+    hipLaunchKernelGGL(trsm_panel_upper_kernel, dim3((M + 63) / 64), dim3(64), 0, s, X, M, ldx, Ukk, ldu);
+}
+void gpk_transpose(hipStream_t s, double *dst, int ldd, const double *src, int lds, int rows, int cols) {
+    if (rows <= 0 || cols <= 0) return;
+    hipLaunchKernelGGL(transpose_kernel, dim3((rows + 63) / 64, (cols + 63) / 64), dim3(256), 0, s, dst, ldd, src, lds, rows, cols);
+}
+void gpk_set_identity(hipStream_t s, double *A, int n, int lda) {
+    hipLaunchKernelGGL(set_identity_kernel, dim3(1024), dim3(256), 0, s, A, n, lda);
+}
+int gpk_lml_grad_partials_size(int n, int d) {
+    int nb = (n + TR_T - 1) / TR_T;
+    return nb * (nb + 1) / 2 * (d + 2);
+}
+void gpk_lml_grad_traces(hipStream_t s, const double *X, int n, int d, int ldx, const double *theta, const double *alpha,
+                         const double *Kinv, int ldk, double *partials, double *out) {
+    TraceParams prm;
+    TraceScale sc;
+    const double sf = theta[0], sn = theta[d + 1];
+    for (int k = 0; k < TR_DMAX; ++k) prm.inv_ls2[k] = 0.0;
+    for (int k = 0; k < TR_DMAX + 2; ++k) sc.s[k] = 0.0;
+    sc.s[0] = sf;
+    for (int k = 0; k < d; ++k) {
+        const double l = theta[1 + k];
+        prm.inv_ls2[k] = 1.0 / (l * l);
+        sc.s[1 + k] = 0.5 * sf * sf / (l * l * l);
+    }
+    sc.s[d + 1] = sn;
+    int nb = (n + TR_T - 1) / TR_T, nblocks = nb * (nb + 1) / 2;
+    hipLaunchKernelGGL(lml_grad_trace_kernel, dim3(nblocks), dim3(256), 0, s, X, n, d, ldx, prm, alpha, Kinv, ldk, partials);
+    hipLaunchKernelGGL(lml_grad_reduce_kernel, dim3(d + 2), dim3(256), 0, s, partials, nblocks, d + 2, sc, out);
+}
+
+int gpk_init_kernels() {
+    // > 64 KiB of dynamic LDS needs an explicit opt-in per kernel
+    const int lds = (int)((NB * LS + NB) * sizeof(double));
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(potrf_diag_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(trsv_diag_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    return e == hipSuccess ? 0 : 1;
+}
+
+void gpk_potrf_diag(hipStream_t s, double *A, int lda, int *d_info, int base) {
+    size_t lds = (size_t)(NB * LS + NB) * sizeof(double);
+    hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), lds, s, A, lda, d_info, base);
+}
+void gpk_trsm_panel(hipStream_t s, double *X, int M, int ldx, const double *Lkk, int ldl, double *sumsq) {
+    if (M <= 0) return;
+    hipLaunchKernelGGL(trsm_panel_kernel, dim3((M + 63) / 64), dim3(64), 0, s, X, M, ldx, Lkk, ldl, sumsq);
+}
+void gpk_gemv_panel_sub(hipStream_t s, const double *A, int M, int lda, const double *x, double *y) {
+    if (M <= 0) return;
+    hipLaunchKernelGGL(gemv_panel_sub_kernel, dim3((M + 255) / 256), dim3(256), 0, s, A, M, lda, x, y);
+}
+void gpk_gemvT_panel_sub(hipStream_t s, const double *A, int M, int lda, const double *x, double *y) {
+    if (M <= 0) return;
+    hipLaunchKernelGGL(gemvT_panel_sub_kernel, dim3(NB), dim3(256), 0, s, A, M, lda, x, y);
+}
+void gpk_trsv_diag(hipStream_t s, const double *Lkk, int ldl, double *b, int trans) {
+    size_t lds = (size_t)(NB * LS + NB) * sizeof(double);
+    hipLaunchKernelGGL(trsv_diag_kernel, dim3(1), dim3(128), lds, s, Lkk, ldl, b, trans);
+}
+void gpk_gemv_rows(hipStream_t s, const double *Ks, int m, int n, int ldks, const double *alpha, double *out, double *partial, int nchunk) {
+    hipLaunchKernelGGL(gemv_rows_kernel, dim3((m + 255) / 256, nchunk), dim3(256), 0, s, Ks, m, n, ldks, alpha, partial, nchunk);
+    hipLaunchKernelGGL(reduce_chunks_kernel, dim3((m + 255) / 256), dim3(256), 0, s, partial, m, nchunk, out);
+}
+void gpk_lml(hipStream_t s, const double *L, int n, int ldl, const double *y, const double *alpha, double *out) {
+    hipLaunchKernelGGL(lml_kernel, dim3(1), dim3(1024), 0, s, L, n, ldl, y, alpha, out);
+}
+void gpk_var_finish(hipStream_t s, double *var, const double *sumsq, int m, double kss) {
+    hipLaunchKernelGGL(var_finish_kernel, dim3((m + 255) / 256), dim3(256), 0, s, var, sumsq, m, kss);
+}

@@ -1,0 +1,147 @@
+/*
+ * gpcore.h -- flat C-ABI of libgpcore.so, the MI355X-native (gfx950) Gaussian-process hot path.
+ *
+ * This header is the drop-in boundary: a JNI / ctypes / cgo binding needs
+ * nothing but these declarations.  No C++ or torch types cross it: plain pointers, ints, doubles.
+ * Every entry point names the reference code it replaces (paths relative to
+ * /root/reference/src/main/scala/).
+ *
+ * Conventions
+ *  - All matrices are COLUMN-MAJOR with an explicit leading dimension, matching Breeze
+ *    DenseMatrix (data, offset, majorStride): element (i,j) = ptr[i + j*ld].
+ *  - theta = [sf, l_1 .. l_d, sn], length d+2, the order of GaussianRbfParams.toDenseVector
+ *    (utils/KernelRequisites.scala:48-52).  sf and sn enter the kernel SQUARED.
+ *  - Host-pointer entry points copy in/out and never retain host pointers past the call.
+ *    `_dev` entry points take device pointers (memory already resident in HBM) and run
+ *    asynchronously on the context's stream; call gp_ctx_sync() before reading results.
+ *  - Every function returns a gp_status; gp_last_error(ctx) gives the message.  Nothing aborts,
+ *    nothing prints.  There is NO CPU fallback: without a usable GPU gp_ctx_create fails.
+ *  - A context is bound to one device and one stream; calls on one context are serialised by the
+ *    caller; different contexts may be used from different threads.
+ */
+#ifndef GPCORE_H
+#define GPCORE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum gp_status {
+    GP_OK = 0,
+    GP_EINVAL = 1, /* bad argument (Scala: require/assert -> IllegalArgumentException)           */
+    GP_ENOTPD = 2, /* matrix not positive definite; *info = 1-based failing pivot (Breeze throws)  */
+    GP_ENOMEM = 3, /* host or device allocation failed                                            */
+    GP_EHIP = 4,   /* HIP runtime error (message in gp_last_error)                                */
+    GP_ERANGE = 5  /* 1-based hyper-parameter position out of range (Scala: MatchError)           */
+} gp_status;
+
+typedef struct gp_ctx gp_ctx;     /* device + stream + workspaces                                  */
+typedef struct gp_model gp_model; /* fitted regression model: X, L, alpha resident in HBM          */
+typedef struct gp_ep gp_ep;       /* EP classification state: K, Sigma, L, site parameters in HBM  */
+
+/* ---- library / context ------------------------------------------------------------------- */
+const char *gp_version(void);
+/* device = HIP ordinal.  stream = NULL: the context creates its own stream; otherwise an existing
+ * hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) is adopted, not owned. */
+gp_status gp_ctx_create(int device, void *stream, gp_ctx **out);
+void gp_ctx_destroy(gp_ctx *ctx);
+gp_status gp_ctx_sync(gp_ctx *ctx);
+const char *gp_last_error(const gp_ctx *ctx);
+/* Per-kernel timing with HIP events on the context's stream.  While enabled, every launch of the
+ * kernel class `which` is bracketed by events; gp_ctx_profile_read returns launches, total ms and
+ * the algorithmic work (flops or bytes) those launches carried, then resets the counters. */
+enum { GP_PROF_OFF = 0, GP_PROF_GEMM = 1, GP_PROF_SYRK = 2, GP_PROF_GRAM = 3, GP_PROF_TRSM = 4, GP_PROF_POTRF_DIAG = 5, GP_PROF_NCLASSES = 6 };
+gp_status gp_ctx_profile(gp_ctx *ctx, int which);
+gp_status gp_ctx_profile_read(gp_ctx *ctx, int which, int64_t *launches, double *total_ms, double *work);
+/* fp64 MFMA peak probe: runs a register-only v_mfma_f64_16x16x4_f64 loop on every CU and returns
+ * the measured TFLOP/s (denominator check for roofline fractions). */
+gp_status gp_probe_mfma_f64(gp_ctx *ctx, double *tflops);
+/* device memory helpers for callers without their own allocator (the JNI shim) */
+gp_status gp_dev_alloc(gp_ctx *ctx, size_t bytes, void **dptr);
+gp_status gp_dev_free(gp_ctx *ctx, void *dptr);
+gp_status gp_dev_upload(gp_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+gp_status gp_dev_download(gp_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+
+/* ---- hyper-parameter indexing (integer work, bit-exact) ------------------------------------ */
+/* GaussianRbfParams.getAtPosition, utils/KernelRequisites.scala:40-46: pos is 1-BASED;
+ * pos outside 1..d+2 -> GP_ERANGE (the Scala throws MatchError). */
+gp_status gp_hp_get_at_position(const double *theta, int d, int pos, double *out);
+
+/* ---- Gram matrices -------------------------------------------------------------------------- */
+enum { GP_LOWER = 0, GP_FULL = 1 };
+/* MatrixUtils.buildKernelMatrix(kernel, X)  utils/MatrixUtils.scala:57-70 with
+ * GaussianRbfKernel.apply utils/KernelRequisites.scala:66-72.  K is n x n; the diagonal is exactly
+ * sf*sf + sn*sn.  uplo = GP_FULL mirrors (exactly symmetric), GP_LOWER leaves the strict upper
+ * triangle untouched. */
+gp_status gp_gram_rbf(gp_ctx *ctx, const double *X, int n, int d, int ldx, const double *theta, double *K, int ldk, int uplo);
+gp_status gp_gram_rbf_dev(gp_ctx *ctx, const double *dX, int n, int d, int ldx, const double *theta, double *dK, int ldk, int uplo);
+/* MatrixUtils.buildKernelMatrix(kernel, X*, X)  utils/MatrixUtils.scala:44-55,86-97 (never adds
+ * noise).  Ks is m x n. */
+gp_status gp_cross_gram_rbf(gp_ctx *ctx, const double *Xs, int m, int ldxs, const double *X, int n, int ldx, int d, const double *theta, double *Ks, int ldks);
+
+/* ---- dense factorisation / solves ----------------------------------------------------------- */
+/* breeze.linalg.cholesky (call sites gp/regression/GpPredictor.scala:120,
+ * gp/classification/EpParameterEstimator.scala:58): A (n x n, lower triangle read) is replaced
+ * by L with a ZERO strict upper triangle.  Not PD -> GP_ENOTPD and *info = 1-based pivot. */
+gp_status gp_potrf_lower(gp_ctx *ctx, double *A, int n, int lda, int *info);
+/* MatrixUtils.forwardSolve / backSolve, utils/MatrixUtils.scala:17-35,115-133.
+ * trans = 0: solve L X = B (forwardSolve(L, B)); trans = 1: solve L^T X = B (backSolve(L.t, B)).
+ * B (n x nrhs) is overwritten by X. */
+gp_status gp_trsm_lower(gp_ctx *ctx, int trans, const double *L, int n, int ldl, double *B, int nrhs, int ldb);
+/* MatrixUtils.invTriangular(L, isUpper=false), utils/MatrixUtils.scala:106-113 */
+gp_status gp_inv_lower(gp_ctx *ctx, const double *L, int n, int ldl, double *Linv, int ldi);
+
+/* ---- GP regression --------------------------------------------------------------------------- */
+/* GpPredictor.preComputeComponents, gp/regression/GpPredictor.scala:104-124.
+ * sigma_noise = NaN means None; a number is added UN-SQUARED to the diagonal (:116). */
+gp_status gp_fit_rbf(gp_ctx *ctx, const double *X, int n, int d, int ldx, const double *y, const double *theta, double sigma_noise, gp_model **out, int *info);
+gp_status gp_fit_rbf_dev(gp_ctx *ctx, const double *dX, int n, int d, int ldx, const double *dy, const double *theta, double sigma_noise, gp_model **out, int *info);
+/* Same with a host-built Gram matrix (any KernelFunc, e.g. Co2Kernel gp/regression/Co2Prediction.scala:29).
+ * Such a model supports gp_model_get and gp_predict_from_cross only. */
+gp_status gp_fit_from_gram(gp_ctx *ctx, const double *K, int n, int ldk, const double *y, gp_model **out, int *info);
+/* Re-fit an existing model in place (same n, d): no allocation, fully asynchronous. */
+gp_status gp_model_refit_dev(gp_model *model, const double *theta, double sigma_noise);
+gp_status gp_model_status(gp_model *model, int *info); /* syncs; GP_ENOTPD if the last (re)fit failed */
+enum { GP_GET_L = 0, GP_GET_ALPHA = 1, GP_GET_LML = 2 };
+/* afterLearningComponents = (L, alpha, _) GpPredictor.scala:157; LML = GpPredictor.logLikelihood :144-149.
+ * GP_GET_L: out is n x n with ld (zero strict upper); GP_GET_ALPHA: n doubles; GP_GET_LML: 1 double. */
+gp_status gp_model_get(gp_model *model, int what, double *out, int ld);
+void gp_model_destroy(gp_model *model);
+/* GpPredictor.predict / computePosterior, gp/regression/GpPredictor.scala:24-58:
+ * mean = K* alpha; V = L \ K*^T; Sigma* = Gram(X*) - V^T V whose diagonal carries sf^2 + sn^2.
+ * mean[m] required; var_diag[m] optional (diag only); cov (m x m, ldc) optional (full, small m). */
+gp_status gp_predict(gp_model *model, const double *Xs, int m, int ldxs, double *mean, double *var_diag, double *cov, int ldc);
+/* device-resident variant: dXs (m x d), dmean[m], dvar[m] in HBM; asynchronous. */
+gp_status gp_predict_dev(gp_model *model, const double *dXs, int m, int ldxs, double *dmean, double *dvar);
+
+/* ---- log marginal likelihood + gradient ------------------------------------------------------ */
+/* GpPredictor.logLikelihoodWithDerivatives, gp/regression/GpPredictor.scala:60-80, evaluated at B
+ * hyper-parameter settings (thetas is B x P row-major: setting b at thetas + b*P, P = d+2), the
+ * batch driven by obtainOptimalHyperParams :126-142 / MeshHyperParamsLogLikelihoodEvaluator.scala:26-40.
+ * nparams = optimizedParamsNum (<= P): only the first nparams gradient components.
+ * lml[B], grad[B x nparams] row-major.  info[B]: 0 or failing pivot per setting (lml = NaN there). */
+gp_status gp_lml_grad_rbf_batched(gp_ctx *ctx, const double *X, int n, int d, int ldx, const double *y, const double *thetas, int B, int nparams, double sigma_noise, double *lml, double *grad, int *info);
+
+/* ---- EP binary classification ---------------------------------------------------------------- */
+/* EpParameterEstimator(kernelMatrix, targets, _), gp/classification/EpParameterEstimator.scala:11-12.
+ * K is any ready-made n x n Gram matrix, y in {-1,+1}. */
+gp_status gp_ep_create(gp_ctx *ctx, const double *K, int n, int ldk, const int32_t *y, gp_ep **out);
+/* nsweeps sweeps of estimateSiteParams :40-62 (site loop + end-of-sweep refactorisation).
+ * tau[n], nu[n] receive the site parameters after the last sweep (either may be NULL). */
+gp_status gp_ep_sweep(gp_ep *ep, int nsweeps, double *tau, double *nu, int *info);
+/* epMarginalLikelihood :71-96.  strict != 0: as compiled (term at :92 dropped); 0: intended formula. */
+gp_status gp_ep_lml(gp_ep *ep, int strict, double *lml);
+enum { GP_EP_GET_L = 0, GP_EP_GET_SIGMA = 1, GP_EP_GET_MU = 2, GP_EP_GET_CAV_TAU = 3, GP_EP_GET_CAV_NU = 4 };
+gp_status gp_ep_get(gp_ep *ep, int what, double *out, int ld);
+/* GpClassifier.classify, gp/classification/GpClassifier.scala:24-47: Ks is m x n (test-train),
+ * kss_diag[m] the diagonal of the test Gram matrix; prob[m] = Phi(mu*_i / sqrt(1 + var*_i)). */
+gp_status gp_ep_predict(gp_ep *ep, const double *Ks, int m, int ldks, const double *kss_diag, double *prob);
+void gp_ep_destroy(gp_ep *ep);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPCORE_H */

@@ -1,0 +1,255 @@
+"""GPU parity tests: every call goes through the C-ABI of libgpcore.so (HIP kernels on gfx950) and is
+compared with the CPU oracle on identical seeded inputs.  Tolerances are the ones BASELINE.md
+section 5 / SURVEY.md section 8(d) state for fp64; integer/indexing work is exact."""
+import numpy as np
+import pytest
+
+from gp_algos_amd import synth
+from oracle import gp_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+TOL_GRAM = 1e-13      # relative, elementwise; diagonal bit-exact
+TOL_CHOL = 1e-13      # ||L L^T - K||_F / ||K||_F
+TOL_MEAN = 1e-9       # relative to max |mean|
+TOL_VAR = 1e-9        # absolute, times sf^2
+TOL_LML = 1e-11       # relative
+TOL_GRAD = 1e-8       # relative to max |grad|
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from gp_algos_amd.core import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def _problem(n, d, m, seed=5, sf=1.3, scale=1.0, sn=0.12):
+    return synth.regression(n, d, m, seed, seed + 1, seed + 2, synth.ard_theta(d, sf, scale, sn))
+
+
+# ---- Gram ---------------------------------------------------------------------------------------
+def test_gram_kat_reference_vectors(ctx):  # MatrixUtilsTest.scala:90-102
+    X = np.array([[2.4, 1.3, 1.9], [2.1, 0.99, 3.1], [1.89, 2.01, 4.0]])
+    K = ctx.gram_rbf(X, [1.0, 1.0, 1.0, 1.0, 0.0])
+    for i in range(3):
+        assert K[i, i] == 1.0
+    np.testing.assert_allclose([K[1, 0], K[2, 0], K[2, 1]],
+                               [0.4435033161650128, 0.07523791396600814, 0.387806024974919], rtol=1e-14)
+    assert np.array_equal(K, K.T)
+
+
+@pytest.mark.parametrize("n,d", [(1, 1), (63, 2), (64, 8), (65, 3), (257, 8), (300, 13), (512, 1)])
+def test_gram_sym_vs_oracle(ctx, n, d):
+    p = _problem(n, d, 0, seed=n + d)
+    K = ctx.gram_rbf(p["X"], p["theta"])
+    Ko = orc.gram_sym(p["X"], p["theta"])
+    assert np.array_equal(np.diag(K), np.diag(Ko))          # sf*sf + sn*sn, bit-exact
+    assert np.array_equal(K, K.T)                             # mirrored, exactly symmetric
+    assert np.max(np.abs(K - Ko) / np.abs(Ko)) <= TOL_GRAM
+
+
+def test_gram_lower_leaves_upper_untouched(ctx):
+    p = _problem(130, 4, 0)
+    out = np.full((130, 130), -7.0, order="F")
+    K = ctx.gram_rbf(p["X"], p["theta"], full=False, out=out)
+    Ko = orc.gram_sym(p["X"], p["theta"])
+    iu = np.triu_indices(130, 1)
+    assert np.all(K[iu] == -7.0)
+    il = np.tril_indices(130)
+    assert np.max(np.abs(K[il] - Ko[il]) / np.abs(Ko[il])) <= TOL_GRAM
+
+
+def test_gram_negative_signal_and_wide_features(ctx):
+    # sf enters squared (spring-context.xml:11 uses a negative signalVar); d > 8 exercises the feature chunks
+    p = _problem(90, 20, 0, sf=-2.5)
+    K = ctx.gram_rbf(p["X"], p["theta"])
+    Ko = orc.gram_sym(p["X"], p["theta"])
+    assert np.max(np.abs(K - Ko) / np.abs(Ko)) <= TOL_GRAM
+
+
+@pytest.mark.parametrize("m,n,d", [(1, 1, 1), (100, 256, 1), (70, 129, 8), (200, 64, 5)])
+def test_cross_gram_vs_oracle(ctx, m, n, d):
+    p = _problem(n, d, m, seed=m + n)
+    Ks = ctx.cross_gram_rbf(p["Xs"], p["X"], p["theta"])
+    Kso = orc.gram_cross(p["Xs"], p["X"], p["theta"])
+    assert Ks.shape == (m, n)
+    assert np.max(np.abs(Ks - Kso) / np.abs(Kso)) <= TOL_GRAM
+
+
+def test_gram_argument_errors(ctx):
+    with pytest.raises(ValueError):      # fromDenseVector require, KernelRequisites.scala:55
+        ctx.gram_rbf(np.zeros((4, 2)), [1.0, 1.0, 0.1])
+
+
+# ---- Cholesky / triangular solves ---------------------------------------------------------------
+@pytest.mark.parametrize("n", [1, 3, 127, 128, 129, 300, 640])
+def test_potrf_vs_oracle(ctx, n):
+    p = _problem(n, 4, 0, seed=n)
+    K = orc.gram_sym(p["X"], p["theta"])
+    L = ctx.potrf_lower(K)
+    assert np.all(np.triu(L, 1) == 0.0)                       # Breeze zeroes the strict upper triangle
+    assert np.linalg.norm(L @ L.T - K) / np.linalg.norm(K) <= TOL_CHOL
+    Lo = orc.cholesky_lower(K)
+    assert np.linalg.norm(L - Lo) / np.linalg.norm(Lo) <= 1e-10   # forward error ~ kappa * eps
+
+
+def test_potrf_reference_kat(ctx):  # MatrixUtilsTest.scala:100 + SURVEY 8c (5)
+    X = np.array([[2.4, 1.3, 1.9], [2.1, 0.99, 3.1], [1.89, 2.01, 4.0]])
+    K = orc.gram_sym(X, [1.0, 1.0, 1.0, 1.0, 0.0])
+    L = ctx.potrf_lower(K)
+    np.testing.assert_allclose(L, [[1, 0, 0], [0.4435033161650128, 0.8962727311207436, 0],
+                                   [0.07523791396600814, 0.3954574855651918, 0.9153975275324375]], rtol=1e-13)
+
+
+def test_potrf_not_positive_definite(ctx):
+    from gp_algos_amd._lib import NotPositiveDefinite
+    A = np.eye(200)
+    A[150, 150] = -1.0
+    with pytest.raises(NotPositiveDefinite) as e:
+        ctx.potrf_lower(A)
+    assert e.value.info == 151
+    with pytest.raises(NotPositiveDefinite) as e:
+        ctx.potrf_lower(np.array([[1.0, 2.0], [2.0, 1.0]]))
+    assert e.value.info == 2
+
+
+def test_trsm_reference_kats(ctx):  # MatrixUtilsTest.scala:24-63
+    Lm = np.array([[0.3, 0.0, 0.0], [0.2, 0.3, 0.0], [0.1, 0.99, 0.11]])
+    U = np.array([[0.4, 0.1, 0.9], [0.0, 0.2, 0.89], [0.0, 0.0, 0.5]])
+    rhs = np.array([[0.4, 0.9], [0.8, 0.3], [0.7, 0.4]])
+    np.testing.assert_allclose(ctx.trsm_lower(Lm, np.array([3.0, 2.0, 1.0])), [10.0, 0.0, 0.0], atol=1e-12)
+    np.testing.assert_allclose(ctx.trsm_lower(Lm, rhs),
+                               [[4 / 3, 3.0], [16 / 9, -1.0], [-10.848484848484848, 9.909090909090908]], rtol=1e-12)
+    # backSolve(R = upper, b): the C-ABI takes the lower factor and trans=1, i.e. R = L^T
+    np.testing.assert_allclose(ctx.trsm_lower(U.T.copy(), np.array([7.0, 3.0, 4.0]), trans=True), [4.65, -20.6, 8.0], rtol=1e-12)
+    np.testing.assert_allclose(ctx.trsm_lower(U.T.copy(), rhs, trans=True),
+                               [[-1.5925, 0.965], [-2.23, -2.06], [1.4, 0.8]], rtol=1e-12)
+
+
+@pytest.mark.parametrize("n,nrhs", [(100, 1), (129, 7), (300, 130), (512, 64)])
+@pytest.mark.parametrize("trans", [False, True])
+def test_trsm_vs_oracle(ctx, n, nrhs, trans):
+    p = _problem(n, 3, 0, seed=n + nrhs, sn=0.3)
+    L = orc.cholesky_lower(orc.gram_sym(p["X"], p["theta"]))
+    rng = np.random.default_rng(n)
+    B = np.asfortranarray(rng.standard_normal((n, nrhs)))
+    X = ctx.trsm_lower(L, B, trans=trans)
+    Xo = orc.back_solve(L, B, trans=True) if trans else orc.forward_solve(L, B)
+    assert np.max(np.abs(X - Xo)) <= 1e-9 * np.max(np.abs(Xo))
+    A = L.T if trans else L
+    assert np.linalg.norm(A @ X - B) / (np.linalg.norm(A) * np.linalg.norm(X)) <= 1e-14
+
+
+def test_inv_lower_kat(ctx):  # MatrixUtilsTest.scala:104-114
+    X = np.array([[2.4, 1.3, 1.9], [2.1, 0.99, 3.1], [1.89, 2.01, 4.0]])
+    K = orc.gram_sym(X, [1.0, 1.0, 1.0, 1.0, 0.0])
+    L = ctx.potrf_lower(K)
+    Li = ctx.inv_lower(L)
+    assert np.max(np.abs(Li.T @ Li - np.linalg.inv(K))) < 1e-3        # the reference's own assertion
+    np.testing.assert_allclose((Li.T @ Li)[0], [1.262170376455613, -0.61551966270158, 0.14373916749199114], rtol=1e-12)
+
+
+# ---- regression: fit, predict, LML --------------------------------------------------------------
+@pytest.mark.parametrize("n,d,m", [(1, 1, 1), (5, 2, 3), (200, 3, 40), (256, 1, 100), (300, 8, 129), (640, 8, 257)])
+def test_fit_predict_vs_oracle(ctx, n, d, m):
+    from gp_algos_amd.core import RegressionModel
+    p = synth.config_c1() if (n, d, m) == (256, 1, 100) else _problem(n, d, m, seed=3 * n + m)
+    mdl = RegressionModel(ctx, p["X"], p["y"], p["theta"])
+    Lo, ao = orc.fit(p["X"], p["y"], p["theta"])
+    K = orc.gram_sym(p["X"], p["theta"])
+    L = mdl.L()
+    assert np.all(np.triu(L, 1) == 0.0)
+    assert np.linalg.norm(L @ L.T - K) / np.linalg.norm(K) <= TOL_CHOL
+    alpha = mdl.alpha()
+    assert np.max(np.abs(alpha - ao)) <= 1e-8 * np.max(np.abs(ao))
+    olml = orc.lml(Lo, ao, p["y"])
+    assert abs(mdl.lml() - olml) <= TOL_LML * abs(olml)
+    mean, var, cov = mdl.predict(p["Xs"], full_cov=True)
+    omean, ovar, ocov, _ = orc.predict(p["X"], p["theta"], Lo, ao, p["Xs"], full_cov=True)
+    sf2 = p["theta"][0] ** 2
+    assert np.max(np.abs(mean - omean)) <= TOL_MEAN * max(1.0, np.max(np.abs(omean)))
+    assert np.max(np.abs(var - ovar)) <= TOL_VAR * sf2
+    assert np.max(np.abs(cov - ocov)) <= TOL_VAR * sf2
+    assert np.array_equal(cov, cov.T)
+    assert np.max(np.abs(np.diag(cov) - var)) <= TOL_VAR * sf2
+    mdl.close()
+
+
+def test_fit_with_sigma_noise_option(ctx):  # GpPredictor.scala:113-119: Some(v) adds v (un-squared) to the diagonal
+    from gp_algos_amd.core import RegressionModel
+    p = _problem(150, 2, 10)
+    mdl = RegressionModel(ctx, p["X"], p["y"], p["theta"], sigma_noise=0.37)
+    Lo, ao = orc.fit(p["X"], p["y"], p["theta"], sigma_noise=0.37)
+    assert np.max(np.abs(mdl.alpha() - ao)) <= 1e-9 * np.max(np.abs(ao))
+    assert np.max(np.abs(mdl.L() - Lo)) <= 1e-11
+    mdl.close()
+
+
+def test_fit_from_gram_any_kernel(ctx):  # host-built Gram (Co2Kernel-style KernelFunc)
+    from gp_algos_amd.core import RegressionModel
+    p = _problem(140, 2, 0)
+    K = orc.gram_sym(p["X"], p["theta"]) + 0.05 * np.eye(140)
+    mdl = RegressionModel(ctx, y=p["y"], gram=K)
+    Lo = orc.cholesky_lower(K)
+    ao = orc.back_solve(Lo, orc.forward_solve(Lo, p["y"]), trans=True)
+    assert np.max(np.abs(mdl.alpha() - ao)) <= 1e-9 * np.max(np.abs(ao))
+    assert abs(mdl.lml() - orc.lml(Lo, ao, p["y"])) <= TOL_LML * abs(orc.lml(Lo, ao, p["y"]))
+    mdl.close()
+
+
+def test_fit_errors_match_reference_conventions(ctx):
+    from gp_algos_amd._lib import NotPositiveDefinite
+    from gp_algos_amd.core import RegressionModel
+    p = _problem(20, 2, 0)
+    with pytest.raises(ValueError):      # require(trainingData.rows == targets.length), GpPredictor.scala:108
+        RegressionModel(ctx, p["X"], p["y"][:-1], p["theta"])
+    Xdup = np.asfortranarray(np.vstack([p["X"], p["X"]]))   # duplicated points, zero noise -> singular
+    th = p["theta"].copy()
+    th[-1] = 0.0
+    with pytest.raises(NotPositiveDefinite):
+        RegressionModel(ctx, Xdup, np.concatenate([p["y"], p["y"]]), th)
+
+
+# ---- LML gradient (GpPredictor.logLikelihoodWithDerivatives) ------------------------------------
+@pytest.mark.parametrize("n,d", [(60, 1), (200, 3), (333, 8)])
+def test_lml_grad_vs_oracle(ctx, n, d):
+    p = _problem(n, d, 0, seed=n)
+    th2 = p["theta"] * np.concatenate(([1.4], np.linspace(0.7, 1.9, d), [2.0]))
+    thetas = np.stack([p["theta"], th2])
+    lml, grad, info = ctx.lml_grad_batched(p["X"], p["y"], thetas)
+    assert np.all(info == 0)
+    for b in range(2):
+        ol, og = orc.lml_grad(p["X"], p["y"], thetas[b])
+        assert abs(lml[b] - ol) <= TOL_LML * abs(ol)
+        assert np.max(np.abs(grad[b] - og)) <= TOL_GRAD * np.max(np.abs(og))
+    # optimizedParamsNum < P (GpPredictor.scala:130-134 drops the noise parameter)
+    lml2, grad2, _ = ctx.lml_grad_batched(p["X"], p["y"], thetas[:1], nparams=d + 1)
+    assert grad2.shape == (1, d + 1)
+    np.testing.assert_allclose(grad2[0], grad[0][:d + 1], rtol=1e-12)
+
+
+def test_lml_grad_finite_differences(ctx):
+    p = _problem(120, 2, 0)
+    th = p["theta"]
+    lml, grad, _ = ctx.lml_grad_batched(p["X"], p["y"], th[None, :])
+    h = 1e-6
+    for k in range(th.size):
+        tp, tm = th.copy(), th.copy()
+        tp[k] += h
+        tm[k] -= h
+        (lp, lm_), _, _ = ctx.lml_grad_batched(p["X"], p["y"], np.stack([tp, tm]), nparams=0)
+        fd = (lp - lm_) / (2 * h)
+        assert abs(fd - grad[0, k]) <= 1e-5 * max(1.0, abs(grad[0, k]))
+
+
+def test_lml_grad_flags_non_pd_setting(ctx):
+    p = _problem(40, 2, 0)
+    Xdup = np.asfortranarray(np.vstack([p["X"], p["X"]]))
+    y = np.concatenate([p["y"], p["y"]])
+    bad = p["theta"].copy()
+    bad[-1] = 0.0
+    lml, grad, info = ctx.lml_grad_batched(Xdup, y, np.stack([p["theta"], bad]))
+    assert info[0] == 0 and np.isfinite(lml[0])
+    assert info[1] > 0 and np.isnan(lml[1])
