@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the GP hot path on MI355X (BASELINE.json metric).
+
+One "step" = one pass of the hot path over one batch of synthetic input (config C2):
+    ARD-RBF Gram (n=8192, d=8) -> fp64 blocked Cholesky -> alpha, LML  (GpPredictor.preComputeComponents)
+    -> posterior mean + variance at m=65536 test points                  (GpPredictor.predict, diag variance)
+with X, y, X* already resident in HBM.  value = test points / second over the whole job.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): the path shards over test points --
+every rank fits the same model redundantly (no data-path collective; SURVEY.md 8e: refit 0.05 s vs
+broadcasting 0.5 GB of L) and predicts its own m points; weak scaling, value = N*m / max-rank time.
+torch is used for rendezvous/barrier/max-reduce only; all compute goes through libgpcore.so.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_FP64_MFMA_TFLOPS = 78.6   # MI355X vendor fp64 matrix peak; the probe value is printed next to it
+PEAK_HBM_GBS = 8000.0
+
+
+def cpu_baseline(p, L_host, alpha_host, budget_pts):
+    """Oracle (CPU restatement of the reference, 1 thread) timed on a bounded sample of the same workload."""
+    from oracle import gp_oracle as orc
+    orc.build()
+    xs = np.asfortranarray(p["Xs"][:2])
+    t0 = time.perf_counter()
+    orc.predict(p["X"], p["theta"], L_host, alpha_host, xs)
+    per_pt = (time.perf_counter() - t0) / 2
+    k = int(max(2, min(budget_pts, 15.0 / max(per_pt, 1e-6))))
+    xs = np.asfortranarray(p["Xs"][:k])
+    t0 = time.perf_counter()
+    mean, var, _, _ = orc.predict(p["X"], p["theta"], L_host, alpha_host, xs)
+    dt = time.perf_counter() - t0
+    return dict(value=k / dt, unit="points/s", cores=1, kind="port",
+                sample="oracle/gp_oracle.c predict (cross-Gram + scalar forward substitution + variance) of %d of the "
+                       "%d test points against the n=%d factor; L and alpha taken from the GPU fit, CPU fit not timed "
+                       "(oracle dpotf2 at n=%d is minutes)" % (k, p["Xs"].shape[0], p["X"].shape[0], p["X"].shape[0])), mean, var, k
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--n", type=int, default=8192)
+    ap.add_argument("--d", type=int, default=8)
+    ap.add_argument("--m", type=int, default=65536)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    import __graft_entry__ as entry
+    entry.build()
+    from gp_algos_amd import _lib as L, synth
+    from gp_algos_amd.core import Context
+
+    n, d, m = args.n, args.d, args.m
+    p = synth.config_c2(n, d, 0)
+    # every rank predicts its own slice of the test stream (seed 13, offset by rank)
+    i = (np.arange(m, dtype=np.uint64) + np.uint64(rank * m))[:, None]
+    k = np.arange(d, dtype=np.uint64)[None, :]
+    p["Xs"] = np.asfortranarray(-2.0 + 4.0 * synth.u(13, i * np.uint64(d) + k))
+
+    ctx = Context(local_rank)
+    lib = ctx._lib
+    probe = ctx.probe_mfma_f64()
+    dX, dy, dXs = ctx.upload(p["X"]), ctx.upload(p["y"]), ctx.upload(p["Xs"])
+    dmean, dvar = ctx.dev_alloc(8 * m), ctx.dev_alloc(8 * m)
+    theta = L.f64(p["theta"])
+    nan = float("nan")
+    h, info = C.c_void_p(), C.c_int()
+    ctx.check(lib.gp_fit_rbf_dev(ctx.h, dX, n, d, n, dy, L.dptr(theta), nan, C.byref(h), C.byref(info)), info.value)
+
+    def step():
+        ctx.check(lib.gp_model_refit_dev(h, L.dptr(theta), nan))
+        ctx.check(lib.gp_predict_dev(h, dXs, m, m, dmean, dvar))
+
+    def fence():
+        ctx.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    prof_mask = (1 << L.GP_PROF_GEMM) | (1 << L.GP_PROF_SYRK) | (1 << L.GP_PROF_GRAM)
+    ctx.profile(prof_mask)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    ctx.profile(0)
+    g_k, g_ms, g_work = ctx.profile_read(L.GP_PROF_GEMM)
+    s_k, s_ms, s_work = ctx.profile_read(L.GP_PROF_SYRK)
+    r_k, r_ms, r_work = ctx.profile_read(L.GP_PROF_GRAM)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # stage breakdown (untimed, rank 0 only needs it)
+    ctx.sync()
+    t1 = time.perf_counter()
+    ctx.check(lib.gp_model_refit_dev(h, L.dptr(theta), nan))
+    ctx.sync()
+    t_fit = time.perf_counter() - t1
+    t1 = time.perf_counter()
+    ctx.check(lib.gp_predict_dev(h, dXs, m, m, dmean, dvar))
+    ctx.sync()
+    t_pred = time.perf_counter() - t1
+    ctx.check(lib.gp_model_status(h, C.byref(info)), info.value)
+
+    out = None
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = world * m * args.steps / dt
+        gemm_tflops = g_work / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
+        syrk_tflops = s_work / (s_ms * 1e-3) / 1e12 if s_ms > 0 else 0.0
+        out = {
+            "metric": "GP posterior (mu,var) points/sec at n=%d fp64 (fit + predict per step)" % n,
+            "value": value, "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "C2: GP regression, ARD-RBF, n=%d d=%d fp64, Gram + Cholesky + posterior mean/variance at m=%d "
+                                   "test points per GPU" % (n, d, m), "n": n, "d": d, "m_per_gpu": m,
+                       "parallelism": "test points sharded %d-way, model refit per rank, no data-path collective" % world},
+            "roofline": {"kernel": "gemm_nt_f64_kernel<0> (posterior solve Vt_i -= Vt_<i L_i,<i^T, v_mfma_f64_16x16x4_f64)",
+                         "bound": "mfma", "achieved": gemm_tflops, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": gemm_tflops / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
+                         "launches": g_k, "avg_launch_us": g_ms / max(g_k, 1) * 1e3,
+                         "flops_per_launch_avg": g_work / max(g_k, 1)},
+            "cholesky": {"fit_ms": t_fit * 1e3, "total_tflops": (n ** 3 / 3.0) / t_fit / 1e12,
+                         "trailing_update_tflops": syrk_tflops, "trailing_update_frac_of_peak": syrk_tflops / PEAK_FP64_MFMA_TFLOPS,
+                         "trailing_update_launches": s_k, "panel_width": 128},
+            "gram": {"GBps": r_work / (r_ms * 1e-3) / 1e9 if r_ms > 0 else 0.0, "frac_of_hbm_peak": (r_work / (r_ms * 1e-3) / 1e9) / PEAK_HBM_GBS if r_ms > 0 else 0.0},
+            "predict_only_points_per_s": m / t_pred, "predict_ms": t_pred * 1e3,
+            "mfma_f64_probe_tflops": probe,
+        }
+    # CPU baseline on rank 0 at N=1 only
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        Lh = np.zeros((n, n), order="F")
+        ctx.check(lib.gp_model_get(h, L.GP_GET_L, L.dptr(Lh), n))
+        ah = np.zeros(n)
+        ctx.check(lib.gp_model_get(h, L.GP_GET_ALPHA, L.dptr(ah), n))
+        base, cmean, cvar, kk = cpu_baseline(p, Lh, ah, 256)
+        gmean = ctx.download(dmean, (m,))[:kk]
+        gvar = ctx.download(dvar, (m,))[:kk]
+        base["max_abs_dmean_vs_gpu"] = float(np.max(np.abs(gmean - cmean)))
+        base["max_abs_dvar_vs_gpu"] = float(np.max(np.abs(gvar - cvar)))
+        out["cpu_baseline"] = base
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    lib.gp_model_destroy(h)
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

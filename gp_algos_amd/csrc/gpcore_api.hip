@@ -9,7 +9,7 @@
 // profiling: HIP events on the context's stream around one kernel class
 // ------------------------------------------------------------------------------------------------
 void gp_prof_begin(gp_ctx *ctx, int cls) {
-    if (ctx->prof_which != cls) return;
+    if (!(ctx->prof_which & (1 << cls))) return;
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return;
     (void)hipEventRecord(e0, ctx->stream);
@@ -17,7 +17,7 @@ void gp_prof_begin(gp_ctx *ctx, int cls) {
     ctx->prof[cls].ev.push_back(e1);
 }
 void gp_prof_end(gp_ctx *ctx, int cls, double work) {
-    if (ctx->prof_which != cls) return;
+    if (!(ctx->prof_which & (1 << cls))) return;
     gp_prof_slot &p = ctx->prof[cls];
     if (p.ev.size() < 2) return;
     (void)hipEventRecord(p.ev.back(), ctx->stream);
@@ -248,9 +248,9 @@ gp_status gp_ctx_sync(gp_ctx *ctx) {
 
 const char *gp_last_error(const gp_ctx *ctx) { return ctx ? ctx->err : "null context"; }
 
-gp_status gp_ctx_profile(gp_ctx *ctx, int which) {
-    if (!ctx || which < 0 || which >= GP_PROF_NCLASSES) return GP_EINVAL;
-    ctx->prof_which = which;
+gp_status gp_ctx_profile(gp_ctx *ctx, int mask) {
+    if (!ctx || mask < 0 || mask >= (1 << GP_PROF_NCLASSES)) return GP_EINVAL;
+    ctx->prof_which = mask;
     return GP_OK;
 }
 
