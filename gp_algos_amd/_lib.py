@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libgpcore.so")
 GP_OK, GP_EINVAL, GP_ENOTPD, GP_ENOMEM, GP_EHIP, GP_ERANGE = range(6)
 GP_LOWER, GP_FULL = 0, 1
 GP_GET_L, GP_GET_ALPHA, GP_GET_LML = 0, 1, 2
-GP_PROF_OFF, GP_PROF_GEMM, GP_PROF_SYRK, GP_PROF_GRAM, GP_PROF_TRSM, GP_PROF_POTRF_DIAG = range(6)
+GP_PROF_OFF, GP_PROF_GEMM, GP_PROF_SYRK, GP_PROF_GRAM, GP_PROF_TRSM, GP_PROF_POTRF_DIAG, GP_PROF_PANEL_UPD = range(7)
 GP_EP_GET_L, GP_EP_GET_SIGMA, GP_EP_GET_MU, GP_EP_GET_CAV_TAU, GP_EP_GET_CAV_NU = range(5)
 
 _dp = C.POINTER(C.c_double)

@@ -8,19 +8,19 @@
 // ------------------------------------------------------------------------------------------------
 // profiling: HIP events on the context's stream around one kernel class
 // ------------------------------------------------------------------------------------------------
-void gp_prof_begin(gp_ctx *ctx, int cls) {
+void gp_prof_begin(gp_ctx *ctx, int cls, hipStream_t s) {
     if (!(ctx->prof_which & (1 << cls))) return;
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return;
-    (void)hipEventRecord(e0, ctx->stream);
+    (void)hipEventRecord(e0, s ? s : ctx->stream);
     ctx->prof[cls].ev.push_back(e0);
     ctx->prof[cls].ev.push_back(e1);
 }
-void gp_prof_end(gp_ctx *ctx, int cls, double work) {
+void gp_prof_end(gp_ctx *ctx, int cls, double work, hipStream_t s) {
     if (!(ctx->prof_which & (1 << cls))) return;
     gp_prof_slot &p = ctx->prof[cls];
     if (p.ev.size() < 2) return;
-    (void)hipEventRecord(p.ev.back(), ctx->stream);
+    (void)hipEventRecord(p.ev.back(), s ? s : ctx->stream);
     p.launches += 1;
     p.work += work;
 }
@@ -74,52 +74,79 @@ gp_status read_info(gp_ctx *ctx, int *info) {
     return GP_OK;
 }
 
-double syrk_flops(int r, int K) {  // lower-triangle tiles incl. full diagonal tiles
-    double nb = r / (double)GP_NB;
-    return nb * (nb + 1) / 2.0 * 2.0 * GP_NB * GP_NB * (double)K;
+double trapezoid_flops(int M, int N, int K) {  // lower-trapezoid tiles (bi >= bj), full diagonal tiles
+    double nbm = M / (double)GP_NB, nbn = N / (double)GP_NB;
+    return (nbn * nbm - nbn * (nbn - 1) / 2.0) * 2.0 * GP_NB * GP_NB * (double)K;
 }
+double syrk_flops(int r, int K) { return trapezoid_flops(r, r, K); }
 
-// Blocked right-looking Cholesky of the padded np x np matrix A (lower), nb = 128:
-//   potrf_diag(Akk); A21 <- A21 Lkk^-T (trsm_panel); A22 -= A21 A21^T (MFMA syrk).
-// If t != nullptr (length np) the forward solve t <- L^-1 t rides along block by block.
-void chol_blocked(gp_ctx *ctx, double *A, int np, int lda, double *t) {
-    hipStream_t s = ctx->stream;
-    const int nblk = np / GP_NB;
-    for (int k = 0; k < nblk; ++k) {
-        double *Akk = A + (size_t)k * GP_NB + (size_t)k * GP_NB * lda;
-        gp_prof_begin(ctx, GP_PROF_POTRF_DIAG);
-        gpk_potrf_diag(s, Akk, lda, ctx->d_info, k * GP_NB);
-        gp_prof_end(ctx, GP_PROF_POTRF_DIAG, (double)GP_NB * GP_NB * GP_NB / 3.0);
-        if (t) gpk_trsv_diag(s, Akk, lda, t + (size_t)k * GP_NB, 0);
-        const int r = np - (k + 1) * GP_NB;
-        if (r <= 0) continue;
-        double *A21 = Akk + GP_NB;
-        gp_prof_begin(ctx, GP_PROF_TRSM);
-        gpk_trsm_panel(s, A21, r, lda, Akk, lda, nullptr);
-        gp_prof_end(ctx, GP_PROF_TRSM, (double)r * GP_NB * GP_NB);
-        if (t) gpk_gemv_panel_sub(s, A21, r, lda, t + (size_t)k * GP_NB, t + (size_t)(k + 1) * GP_NB);
-        double *A22 = A21 + (size_t)GP_NB * lda;
+// Two-level blocked right-looking Cholesky of the padded np x np matrix A (lower):
+//   inner (nb = 128), confined to one outer panel of GP_OUTER = 512 columns:
+//       potrf_diag128(Akk) -> Lkk + 16x16 tile inverses;  A21 <- A21 Lkk^-T (MFMA trsm panel, all rows below);
+//       the rest of the OUTER PANEL's columns -= A21 A21^T (narrow MFMA update, K = 128)
+//   outer: trailing matrix -= P P^T with K = 512 (the high-intensity MFMA syrk this design is built around),
+//       split into (a) the next outer panel's columns, on the main stream, and (b) everything to the right
+//       of it, on the side stream, so (b) overlaps the latency-bound factorisation of the next panel.
+// `extra` (0 or GP_NB) rows below the matrix ride along: with y^T in row np this leaves (L^-1 y)^T there.
+void chol_blocked(gp_ctx *ctx, double *A, int np, int lda, double *dinv, int extra) {
+    hipStream_t s = ctx->stream, s2 = ctx->side;
+    const int rows = np + extra;
+    bool side_busy = false;
+    for (int K0 = 0; K0 < np; K0 += GP_OUTER) {
+        const int wcols = std::min(GP_OUTER, np - K0);
+        for (int k0 = K0; k0 < K0 + wcols; k0 += GP_NB) {
+            double *Akk = A + (size_t)k0 + (size_t)k0 * lda;
+            double *dk = dinv + (size_t)k0 * 16;
+            gp_prof_begin(ctx, GP_PROF_POTRF_DIAG);
+            gpk_potrf_diag128(s, Akk, lda, dk, ctx->d_info, k0);
+            gp_prof_end(ctx, GP_PROF_POTRF_DIAG, (double)GP_NB * GP_NB * GP_NB / 3.0);
+            const int r = rows - (k0 + GP_NB);
+            if (r <= 0) continue;
+            double *A21 = Akk + GP_NB;
+            gp_prof_begin(ctx, GP_PROF_TRSM);
+            gpk_trsm_panel128(s, A21, r, lda, Akk, lda, dk, nullptr);
+            gp_prof_end(ctx, GP_PROF_TRSM, (double)r * GP_NB * GP_NB);
+            const int wc = K0 + wcols - (k0 + GP_NB);
+            if (wc > 0) {
+                gp_prof_begin(ctx, GP_PROF_PANEL_UPD);
+                gpk_gemm_nt(s, r, wc, GP_NB, -1.0, A21, lda, A21, lda, 1.0, A21 + (size_t)GP_NB * lda, lda, 1);
+                gp_prof_end(ctx, GP_PROF_PANEL_UPD, trapezoid_flops(r, wc, GP_NB));
+            }
+        }
+        const int c1 = K0 + wcols;
+        const int R = np - c1;
+        if (R <= 0) break;
+        if (side_busy) { (void)hipStreamWaitEvent(s, ctx->ev_b, 0); side_busy = false; }
+        const double *P = A + (size_t)c1 + (size_t)K0 * lda;
+        const int nnext = ctx->lookahead ? std::min(GP_OUTER, R) : R;
+        if (R > nnext) {
+            (void)hipEventRecord(ctx->ev_a, s);          // outer panel K0 is complete at this point
+            (void)hipStreamWaitEvent(s2, ctx->ev_a, 0);
+            const int c2 = c1 + nnext;
+            const double *P2 = A + (size_t)c2 + (size_t)K0 * lda;
+            gp_prof_begin(ctx, GP_PROF_SYRK, s2);
+            gpk_gemm_nt(s2, rows - c2, np - c2, wcols, -1.0, P2, lda, P2, lda, 1.0, A + (size_t)c2 + (size_t)c2 * lda, lda, 1);
+            gp_prof_end(ctx, GP_PROF_SYRK, trapezoid_flops(rows - c2, np - c2, wcols), s2);
+            (void)hipEventRecord(ctx->ev_b, s2);
+            side_busy = true;
+        }
         gp_prof_begin(ctx, GP_PROF_SYRK);
-        gpk_gemm_nt(s, r, r, GP_NB, -1.0, A21, lda, A21, lda, 1.0, A22, lda, 1);
-        gp_prof_end(ctx, GP_PROF_SYRK, syrk_flops(r, GP_NB));
+        gpk_gemm_nt(s, rows - c1, nnext, wcols, -1.0, P, lda, P, lda, 1.0, A + (size_t)c1 + (size_t)c1 * lda, lda, 1);
+        gp_prof_end(ctx, GP_PROF_SYRK, trapezoid_flops(rows - c1, nnext, wcols));
     }
+    if (side_busy) (void)hipStreamWaitEvent(s, ctx->ev_b, 0);
 }
 
-// alpha <- L^-T t (block back substitution), in place on t
-void back_solve_vec(gp_ctx *ctx, const double *L, int np, int ldl, double *t) {
+// alpha <- L^-T z: block backward substitution, one fused launch per block step (z is consumed).
+void back_solve_vec(gp_ctx *ctx, const double *L, int np, int ldl, const double *dinv, double *z, double *alpha) {
     hipStream_t s = ctx->stream;
-    const int nblk = np / GP_NB;
-    for (int k = nblk - 1; k >= 0; --k) {
-        const double *Lkk = L + (size_t)k * GP_NB + (size_t)k * GP_NB * ldl;
-        const int r = np - (k + 1) * GP_NB;
-        if (r > 0) gpk_gemvT_panel_sub(s, Lkk + GP_NB, r, ldl, t + (size_t)(k + 1) * GP_NB, t + (size_t)k * GP_NB);
-        gpk_trsv_diag(s, Lkk, ldl, t + (size_t)k * GP_NB, 1);
-    }
+    for (int k = np / GP_NB - 1; k >= 0; --k)
+        gpk_bwd_step(s, L, ldl, dinv + (size_t)k * GP_NB * 16, z, alpha, k * GP_NB);
 }
 
 // Vt (mp x np, ld mp) <- Vt * L^-T, block column by block column (forwardSolve(L, K*^T) transposed).
 // sumsq (length mp) accumulates row sums of squares of the result when non-null.
-void solve_rows_lower(gp_ctx *ctx, double *Vt, int mp, const double *L, int np, int ldl, double *sumsq) {
+void solve_rows_lower(gp_ctx *ctx, double *Vt, int mp, const double *L, int np, int ldl, const double *dinv, double *sumsq) {
     hipStream_t s = ctx->stream;
     const int nblk = np / GP_NB;
     for (int i = 0; i < nblk; ++i) {
@@ -130,7 +157,7 @@ void solve_rows_lower(gp_ctx *ctx, double *Vt, int mp, const double *L, int np, 
             gp_prof_end(ctx, GP_PROF_GEMM, 2.0 * mp * GP_NB * (double)i * GP_NB);
         }
         gp_prof_begin(ctx, GP_PROF_TRSM);
-        gpk_trsm_panel(s, Vi, mp, mp, L + (size_t)i * GP_NB + (size_t)i * GP_NB * ldl, ldl, sumsq);
+        gpk_trsm_panel128(s, Vi, mp, mp, L + (size_t)i * GP_NB + (size_t)i * GP_NB * ldl, ldl, dinv + (size_t)i * GP_NB * 16, sumsq);
         gp_prof_end(ctx, GP_PROF_TRSM, (double)mp * GP_NB * GP_NB);
     }
 }
@@ -155,15 +182,17 @@ void solve_rows_upper(gp_ctx *ctx, double *Vt, int mp, const double *U, int np, 
 gp_status model_alloc(gp_ctx *ctx, int n, int d, bool has_x, gp_model **out) {
     gp_model *m = new (std::nothrow) gp_model();
     if (!m) return GP_ENOMEM;
-    m->ctx = ctx; m->n = n; m->d = d; m->np = gp_pad(n); m->has_x = has_x;
+    m->ctx = ctx; m->n = n; m->d = d; m->np = gp_pad(n); m->ldl = m->np + GP_NB; m->has_x = has_x;
     const size_t np = m->np;
     hipError_t e = hipSuccess;
     if (has_x) e = hipMalloc(&m->dX, sizeof(double) * (size_t)n * d);
     if (e == hipSuccess) e = hipMalloc(&m->dy, sizeof(double) * np);
-    if (e == hipSuccess) e = hipMalloc(&m->dL, sizeof(double) * np * np);
+    if (e == hipSuccess) e = hipMalloc(&m->dL, sizeof(double) * (np + GP_NB) * np);
     if (e == hipSuccess) e = hipMalloc(&m->dalpha, sizeof(double) * np);
     if (e == hipSuccess) e = hipMalloc(&m->dlml, sizeof(double) * 8);
-    if (e == hipSuccess) e = hipMemsetAsync(m->dL, 0, sizeof(double) * np * np, ctx->stream);
+    if (e == hipSuccess) e = hipMalloc(&m->ddinv, sizeof(double) * np * 16);
+    if (e == hipSuccess) e = hipMalloc(&m->dtmp, sizeof(double) * 2 * np);
+    if (e == hipSuccess) e = hipMemsetAsync(m->dL, 0, sizeof(double) * (np + GP_NB) * np, ctx->stream);
     if (e == hipSuccess) e = hipMemsetAsync(m->dy, 0, sizeof(double) * np, ctx->stream);
     if (e != hipSuccess) {
         GP_SET_ERR(ctx, "model allocation (n=%d) failed: %s", n, hipGetErrorString(e));
@@ -174,16 +203,19 @@ gp_status model_alloc(gp_ctx *ctx, int n, int d, bool has_x, gp_model **out) {
     return GP_OK;
 }
 
-// factor the matrix already sitting in model->dL (lower), then alpha and LML
+// factor the matrix already sitting in model->dL (lower), then alpha and LML.
+// y^T rides through the factorisation in row np of dL (forward solve for free), the backward solve follows.
 void model_factor(gp_model *m) {
     gp_ctx *ctx = m->ctx;
     hipStream_t s = ctx->stream;
     (void)hipMemsetAsync(ctx->d_info, 0, sizeof(int), s);
-    gpk_pad_identity(s, m->dL, m->n, m->np, m->np);
-    (void)hipMemcpyAsync(m->dalpha, m->dy, sizeof(double) * m->np, hipMemcpyDeviceToDevice, s);
-    chol_blocked(ctx, m->dL, m->np, m->np, m->dalpha);
-    back_solve_vec(ctx, m->dL, m->np, m->np, m->dalpha);
-    gpk_lml(s, m->dL, m->n, m->np, m->dy, m->dalpha, m->dlml);
+    gpk_pad_identity(s, m->dL, m->n, m->np, m->ldl);
+    gpk_copy_strided(s, m->dL + m->np, (size_t)m->ldl, m->dy, 1, m->np);
+    chol_blocked(ctx, m->dL, m->np, m->ldl, m->ddinv, GP_NB);
+    double *z = m->dtmp;
+    gpk_copy_strided(s, z, 1, m->dL + m->np, (size_t)m->ldl, m->np);
+    back_solve_vec(ctx, m->dL, m->np, m->ldl, m->ddinv, z, m->dalpha);
+    gpk_lml(s, m->dL, m->n, m->ldl, m->dy, m->dalpha, m->dlml);
 }
 
 }  // namespace
@@ -214,10 +246,11 @@ gp_status gp_ctx_create(int device, void *stream, gp_ctx **out) {
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_a, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_b, hipEventDisableTiming);
+    if (const char *la = getenv("GPCORE_LOOKAHEAD")) ctx->lookahead = atoi(la) != 0;
     if (e == hipSuccess) e = hipMalloc(&ctx->d_scalars, sizeof(double) * 256);
     if (e == hipSuccess) e = hipMalloc(&ctx->d_info, sizeof(int) * 4);
     if (e == hipSuccess) e = hipMemset(ctx->d_info, 0, sizeof(int) * 4);
-    if (e == hipSuccess && gpk_init_kernels() != 0) e = hipErrorInvalidValue;
+    if (e == hipSuccess && (gpk_init_kernels() != 0 || gpk_init_diag_kernels() != 0)) e = hipErrorInvalidValue;
     if (e != hipSuccess) { delete ctx; return GP_EHIP; }
     *out = ctx;
     return GP_OK;
@@ -369,7 +402,9 @@ gp_status gp_potrf_lower(gp_ctx *ctx, double *A, int n, int lda, int *info) {
     GP_TRY(upload_2d(ctx, dA, np, A, lda, n, n));
     gpk_pad_identity(ctx->stream, dA, n, np, np);
     GP_HIP(ctx, hipMemsetAsync(ctx->d_info, 0, sizeof(int), ctx->stream));
-    chol_blocked(ctx, dA, np, np, nullptr);
+    double *dinv;
+    GP_TRY(ws_get(ctx, WS_E, sizeof(double) * (size_t)np * 16, &dinv));
+    chol_blocked(ctx, dA, np, np, dinv, 0);
     gpk_zero_upper(ctx->stream, dA, n, np);
     int h = 0;
     GP_TRY(read_info(ctx, &h));
@@ -403,7 +438,7 @@ gp_status gp_model_refit_dev(gp_model *m, const double *theta, double sigma_nois
     m->theta.assign(theta, theta + m->d + 2);
     m->sigma_noise = sigma_noise;
     gp_prof_begin(ctx, GP_PROF_GRAM);
-    gpk_gram_sym(ctx->stream, m->dX, m->n, m->d, m->n, theta, m->dL, m->np, 0, std::isnan(sigma_noise) ? 0.0 : sigma_noise);
+    gpk_gram_sym(ctx->stream, m->dX, m->n, m->d, m->n, theta, m->dL, m->ldl, 0, std::isnan(sigma_noise) ? 0.0 : sigma_noise);
     gp_prof_end(ctx, GP_PROF_GRAM, 8.0 * m->n * (m->n + 1.0) / 2.0 + 8.0 * m->n * m->d);
     model_factor(m);
     return GP_OK;
@@ -463,11 +498,11 @@ gp_status gp_fit_from_gram(gp_ctx *ctx, const double *K, int n, int ldk, const d
     GP_HIP(ctx, hipSetDevice(ctx->device));
     gp_model *m = nullptr;
     GP_TRY(model_alloc(ctx, n, 0, false, &m));
-    gp_status st = upload_2d(ctx, m->dL, m->np, K, ldk, n, n);
+    gp_status st = upload_2d(ctx, m->dL, m->ldl, K, ldk, n, n);
     if (st == GP_OK) st = upload_2d(ctx, m->dy, n, y, n, n, 1);
     if (st == GP_OK) {
         model_factor(m);
-        gpk_zero_upper(ctx->stream, m->dL, n, m->np);
+        gpk_zero_upper(ctx->stream, m->dL, n, m->ldl);
         st = gp_model_status(m, info);
     }
     if (st != GP_OK) { gp_model_destroy(m); return st; }
@@ -481,7 +516,7 @@ gp_status gp_model_get(gp_model *m, int what, double *out, int ld) {
     switch (what) {
         case GP_GET_L:
             GP_REQUIRE(ctx, ld >= m->n, "ld < n");
-            return download_2d(ctx, out, ld, m->dL, m->np, m->n, m->n);
+            return download_2d(ctx, out, ld, m->dL, m->ldl, m->n, m->n);
         case GP_GET_ALPHA:
             return download_2d(ctx, out, m->n, m->dalpha, m->np, m->n, 1);
         case GP_GET_LML:
@@ -499,7 +534,8 @@ void gp_model_destroy(gp_model *m) {
     if (m->dy) (void)hipFree(m->dy);
     if (m->dL) (void)hipFree(m->dL);
     if (m->dalpha) (void)hipFree(m->dalpha);
-    if (m->dwork) (void)hipFree(m->dwork);
+    if (m->ddinv) (void)hipFree(m->ddinv);
+    if (m->dtmp) (void)hipFree(m->dtmp);
     if (m->dlml) (void)hipFree(m->dlml);
     delete m;
 }
@@ -523,7 +559,7 @@ static gp_status predict_core(gp_model *mdl, const double *dXs, int m, int ldxs,
     gp_prof_end(ctx, GP_PROF_GRAM, 8.0 * m * (double)n + 8.0 * (m + n) * mdl->d);
     gpk_gemv_rows(s, Vt, m, n, mp, mdl->dalpha, dmean, partial, nchunk);
     GP_HIP(ctx, hipMemsetAsync(sumsq, 0, sizeof(double) * mp, s));
-    solve_rows_lower(ctx, Vt, mp, mdl->dL, np, np, sumsq);
+    solve_rows_lower(ctx, Vt, mp, mdl->dL, np, mdl->ldl, mdl->ddinv, sumsq);
     if (dvar) {
         const double sf = mdl->theta[0], sn = mdl->theta[mdl->d + 1];
         gpk_var_finish(s, dvar, sumsq, m, sf * sf + sn * sn);
@@ -598,7 +634,10 @@ static gp_status trsm_impl(gp_ctx *ctx, int trans, const double *L, int n, int l
     GP_TRY(upload_2d(ctx, dB, np, B, ldb, n, nrhs));
     gpk_transpose(s, dVt, mp, dB, np, np, mp);  // Vt = B^T  (mp x np)
     if (!trans) {
-        solve_rows_lower(ctx, dVt, mp, dL, np, np, nullptr);
+        double *dinv;
+        GP_TRY(ws_get(ctx, WS_C, sizeof(double) * (size_t)np * 16, &dinv));
+        gpk_tile_inverses(s, dL, np, np, dinv);
+        solve_rows_lower(ctx, dVt, mp, dL, np, np, dinv, nullptr);
     } else {
         double *dU;
         GP_TRY(ws_get(ctx, WS_E, sizeof(double) * (size_t)np * np, &dU));
@@ -641,7 +680,7 @@ extern "C" gp_status gp_lml_grad_rbf_batched(gp_ctx *ctx, const double *X, int n
         if (st != GP_OK) break;
         if (nparams > 0) {
             gpk_set_identity(s, T, np, np);
-            solve_rows_lower(ctx, T, np, m->dL, np, np, nullptr);       // T = L^-T (upper triangular)
+            solve_rows_lower(ctx, T, np, m->dL, np, m->ldl, m->ddinv, nullptr);   // T = L^-T (upper triangular)
             gp_prof_begin(ctx, GP_PROF_SYRK);
             gpk_gemm_nt(s, np, np, np, 1.0, T, np, T, np, 0.0, Kinv, np, 1, 1);  // Kinv = T T^T, lower
             gp_prof_end(ctx, GP_PROF_SYRK, (double)np * np * np / 3.0);

@@ -4,6 +4,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <cmath>
 #include <vector>
 
@@ -13,6 +14,7 @@
 // identity in the pad block, so chol([[K,0],[0,I]]) = [[L,0],[0,I]] and no kernel needs edge guards.
 constexpr int GP_NB = 128;   // Cholesky panel width == GEMM tile edge
 constexpr int GP_BK = 16;    // GEMM k-step
+constexpr int GP_OUTER = 512; // outer panel width of the two-level Cholesky (trailing update runs with K = 512)
 static inline int gp_pad(int n) { return (n + GP_NB - 1) / GP_NB * GP_NB; }
 
 struct gp_prof_slot {
@@ -30,6 +32,7 @@ struct gp_ctx {
     int prof_which = GP_PROF_OFF;
     gp_prof_slot prof[GP_PROF_NCLASSES];
     int num_cu = 256;
+    bool lookahead = true;        // overlap the far trailing update with the next panel (GPCORE_LOOKAHEAD=0 disables)
     char err[512] = {0};
     // scratch reused across calls
     double *d_scalars = nullptr;  // small device scratch (256 doubles)
@@ -39,12 +42,14 @@ struct gp_ctx {
 struct gp_model {
     gp_ctx *ctx = nullptr;
     int n = 0, d = 0, np = 0;        // np = padded n
+    int ldl = 0;                     // leading dimension of dL = np + GP_NB: one extra row strip carries y^T through the factorisation
     bool has_x = false;              // false for gp_fit_from_gram
     double *dX = nullptr;            // n x d, ld = n
     double *dy = nullptr;            // np
-    double *dL = nullptr;            // np x np, ld = np
+    double *dL = nullptr;            // (np + GP_NB) x np, ld = ldl; row np holds y^T -> (L^-1 y)^T
     double *dalpha = nullptr;        // np
-    double *dwork = nullptr;         // np x GP_NB panel workspace
+    double *ddinv = nullptr;         // np x 16: inverses of the 16x16 diagonal tiles of L
+    double *dtmp = nullptr;          // np: intermediate L^-1 y
     double *dlml = nullptr;          // 1 double on device
     std::vector<double> theta;       // d + 2
     double sigma_noise = NAN;
@@ -58,12 +63,12 @@ struct gp_model {
 #define GP_TRY(call) do { gp_status s_ = (call); if (s_ != GP_OK) return s_; } while (0)
 
 // ---- profiling helpers (gpcore_api.hip) ----
-void gp_prof_begin(gp_ctx *ctx, int cls);
-void gp_prof_end(gp_ctx *ctx, int cls, double work);
+void gp_prof_begin(gp_ctx *ctx, int cls, hipStream_t s = nullptr);
+void gp_prof_end(gp_ctx *ctx, int cls, double work, hipStream_t s = nullptr);
 
 // ---- kernel launchers (each asynchronous on `s`) ----
 // C[MxN] = beta*C + alpha * A[MxK] * B[NxK]^T, column-major; M,N multiples of 128, K multiple of 16.
-// lower != 0: M == N, only tiles on/below the diagonal are computed; on diagonal tiles only i >= j is stored.
+// lower != 0: M >= N, only tiles on/below the diagonal (bi >= bj) are computed; on diagonal tiles only i >= j is stored.
 // ktri != 0: A(i,k) is zero for k < i (upper-triangular operand): each tile starts its k loop at its row block.
 void gpk_gemm_nt(hipStream_t s, int M, int N, int K, double alpha, const double *A, int lda, const double *B, int ldb,
                  double beta, double *C, int ldc, int lower, int ktri = 0);
@@ -102,3 +107,13 @@ void gpk_var_finish(hipStream_t s, double *var, const double *sumsq, int m, doub
 void gpk_copy_2d(hipStream_t s, double *dst, int ldd, const double *src, int lds, int rows, int cols);
 double gpk_probe_mfma(hipStream_t s, int num_cu);
 int gpk_init_kernels();
+int gpk_init_diag_kernels();
+// MFMA-blocked critical-path kernels (kernels_diag.hip).  dinv holds the inverses of the 16x16 diagonal
+// tiles of L: tile b (rows 16b..16b+15) at dinv + 256*b, element (c,k) at c + 16k; a 128-block owns 8 tiles.
+void gpk_potrf_diag128(hipStream_t s, double *A, int lda, double *dinv_k, int *d_info, int base);
+void gpk_trsm_panel128(hipStream_t s, double *X, int M, int ldx, const double *Lkk, int ldl, const double *dinv_k, double *sumsq);
+void gpk_fwd_step(hipStream_t s, const double *L, int ldl, const double *dinv_k, double *t, double *sol, int k0, int r);
+void gpk_bwd_step(hipStream_t s, const double *L, int ldl, const double *dinv_k, double *t, double *sol, int k0);
+void gpk_tile_inverses(hipStream_t s, const double *L, int np, int ldl, double *dinv);
+// dst[j*dst_stride] = src[j*src_stride], j < count
+void gpk_copy_strided(hipStream_t s, double *dst, size_t dst_stride, const double *src, size_t src_stride, int count);

@@ -1,0 +1,387 @@
+// Critical-path kernels of the blocked fp64 Cholesky and triangular solves, MFMA-blocked at 16 (gfx950).
+//
+//   potrf_diag128 : Cholesky of one 128x128 diagonal block held in LDS.  Per 16-column micro-panel:
+//                   the 16x16 diagonal tile is factored and inverted in registers by one wave
+//                   (v_readlane broadcasts, no LDS round trips), the panel below is multiplied by the
+//                   tile inverse on the matrix cores, and the rest of the block is updated with
+//                   v_mfma_f64_16x16x4_f64 straight out of LDS.  Emits the 8 tile inverses ("dinv").
+//   trsm_panel128 : X (M x 128) <- X * Lkk^-T.  64 rows per workgroup, X strip in LDS, blocked forward
+//                   substitution: GEMM part on MFMA (L fragments from L2), 16x16 solves by the tile
+//                   inverses, feeding the accumulator registers directly back as the next B operand.
+//   fwd/bwd_step  : one block step of t <- L^-1 t / alpha <- L^-T t: every workgroup re-solves the
+//                   128x128 diagonal system in LDS (cheap) and applies its share of the panel update.
+//
+// Reference semantics: breeze.linalg.cholesky (GpPredictor.scala:120), MatrixUtils.forwardSolve /
+// backSolve (MatrixUtils.scala:17-35,115-133).  Only the 16x16 tile inverses are explicit inverses;
+// everything larger is substitution, so the backward error stays at the substitution level.
+#include "gpcore_internal.h"
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+typedef double double2_t __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int NB = GP_NB;   // 128
+constexpr int PLS = 144;    // LDS column stride of the 128x128 block: 1152 B = 128 (mod 256) -> conflict-free fragments
+constexpr int XS = 80;      // LDS column stride of the 64-row X strip: 640 B = 128 (mod 256)
+constexpr int LS1 = NB + 1;
+
+__device__ __forceinline__ double rl64(double v, int lane) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+
+// 128x128 block global -> LDS with 16-byte loads, 8 in flight per thread (a serial load/wait/ds_write loop
+// costs ~45 us for this block; batched it is ~2 us).  LOWER: zero the strict upper triangle on the way in.
+template <int STRIDE, bool LOWER>
+__device__ __forceinline__ void load_block_lds(double *a, const double *__restrict__ A, int lda, int tid) {
+#pragma unroll
+    for (int q0 = 0; q0 < 32; q0 += 8) {
+        double2_t v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int e = tid + 256 * (q0 + q), i = (e & 63) * 2, j = e >> 6;
+            v[q] = *reinterpret_cast<const double2_t *>(A + i + (size_t)j * lda);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int e = tid + 256 * (q0 + q), i = (e & 63) * 2, j = e >> 6;
+            a[i + j * STRIDE] = (!LOWER || i >= j) ? v[q].x : 0.0;
+            a[i + 1 + j * STRIDE] = (!LOWER || i + 1 >= j) ? v[q].y : 0.0;
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void potrf_diag128_kernel(double *__restrict__ A, int lda, double *__restrict__ dinv,
+                                                            int *info, int base) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double *a = sm;                 // NB x PLS
+    double *dv = sm + NB * PLS;     // 16 x 16 inverse of the current diagonal tile, (c,k) at c + 16k
+    int *flag = reinterpret_cast<int *>(dv + 256);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    if (tid == 0) *flag = 0;
+    load_block_lds<PLS, true>(a, A, lda, tid);
+    for (int jb = 0; jb < NB / 16; ++jb) {
+        const int c0 = jb * 16;
+        __syncthreads();
+        if (wave == 0) {
+            // ---- 16x16 tile: Cholesky (row owner = lane&15) then inverse (column owner = lane&15) ----
+            double row[16], invd[16], x[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) row[c] = a[(c0 + fr) + (c0 + c) * PLS];
+            int bad = 0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                double ajj = rl64(row[j], j);
+                if (!(ajj > 0.0)) { if (!bad) bad = j + 1; ajj = 1.0; }
+                // 1/sqrt by v_rsq_f64 + two Newton steps, sqrt = a*r with one correction: ~10 dependent FMAs
+                // instead of the ~45-instruction sqrt + divide pair (this chain is on the critical path 16x per tile)
+                double rs = __builtin_amdgcn_rsq(ajj);
+                rs = rs * fma(-0.5 * ajj * rs, rs, 1.5);
+                rs = rs * fma(-0.5 * ajj * rs, rs, 1.5);
+                double djj = ajj * rs;
+                djj = fma(0.5 * rs, fma(-djj, djj, ajj), djj);
+                const double inv = fma(rs, fma(-djj, rs, 1.0), rs);   // 1/djj refined against the rounded djj
+                invd[j] = inv;
+                row[j] = (fr == j) ? djj : row[j] * inv;
+#pragma unroll
+                for (int c = j + 1; c < 16; ++c) {
+                    const double lcj = rl64(row[j], c);
+                    row[c] = fma(-row[j], lcj, row[c]);
+                }
+            }
+            if (lane < 16) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) a[(c0 + fr) + (c0 + c) * PLS] = (c <= fr) ? row[c] : 0.0;
+            }
+            // inverse, column owner = lane&15; D(rr,k) comes back as an LDS broadcast (same address in every lane)
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) {
+                double s = (rr == fr) ? 1.0 : 0.0;
+#pragma unroll
+                for (int k = 0; k < rr; ++k) s = fma(-a[(c0 + rr) + (c0 + k) * PLS], x[k], s);
+                x[rr] = s * invd[rr];
+            }
+            if (lane < 16) {
+#pragma unroll
+                for (int rr = 0; rr < 16; ++rr) {
+                    dv[rr + 16 * fr] = x[rr];
+                    dinv[jb * 256 + rr + 16 * fr] = x[rr];
+                }
+            }
+            if (bad && lane == 0) { atomicCAS(info, 0, base + c0 + bad); *flag = 1; }
+        }
+        __syncthreads();
+        if (*flag) break;
+        // ---- panel below the tile:  P <- A_below * invD^T, computed as (invD * A_below^T) so rows stay on the lane ----
+        const int T = NB / 16 - 1 - jb;
+        for (int t = wave; t < T; t += 4) {
+            const int r0 = c0 + 16 + 16 * t;
+            double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const double aop = dv[fr + 16 * (4 * ks + fg)];
+                const double bop = a[(r0 + fr) + (c0 + 4 * ks + fg) * PLS];
+                acc = MFMA(aop, bop, acc);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a[(r0 + fr) + (c0 + fg + 4 * r) * PLS] = acc[r];
+        }
+        __syncthreads();
+        // ---- rest of the block:  A(ti,tj) -= P_ti P_tj^T  for jb < tj <= ti ----
+        const int ntile = T * (T + 1) / 2;
+        for (int q = wave; q < ntile; q += 4) {
+            int bi = 0;
+            while ((bi + 1) * (bi + 2) / 2 <= q) ++bi;
+            const int bj = q - bi * (bi + 1) / 2;
+            const int ri = c0 + 16 + 16 * bi, rj = c0 + 16 + 16 * bj;
+            double4_t acc;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] = a[(ri + fr) + (rj + fg + 4 * r) * PLS];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const double aop = -a[(rj + fr) + (c0 + 4 * ks + fg) * PLS];
+                const double bop = a[(ri + fr) + (c0 + 4 * ks + fg) * PLS];
+                acc = MFMA(aop, bop, acc);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a[(ri + fr) + (rj + fg + 4 * r) * PLS] = acc[r];
+        }
+    }
+    __syncthreads();
+    if (*flag) return;
+#pragma unroll 8
+    for (int q = 0; q < 32; ++q) {
+        const int e = tid + 256 * q, i = (e & 63) * 2, j = e >> 6;
+        double2_t v;
+        v.x = (i >= j) ? a[i + j * PLS] : 0.0;
+        v.y = (i + 1 >= j) ? a[i + 1 + j * PLS] : 0.0;
+        *reinterpret_cast<double2_t *>(A + i + (size_t)j * lda) = v;
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// L fragments of chunk CB (rows 16*CB.., all previous columns): 4*CB values per lane, A-operand layout.
+template <int CB>
+__device__ __forceinline__ void trsm_load_frags(const double *__restrict__ L, int ldl, int fr, int fg, double (&lf)[28]) {
+#pragma unroll
+    for (int q = 0; q < 4 * CB; ++q) lf[q] = L[(16 * CB + fr) + (size_t)(4 * q + fg) * ldl];
+}
+
+// one 16-column chunk: R = B_cb - X_prev L(cb,prev)^T on the matrix cores, then X_cb = invD_cb R with the
+// accumulator registers fed straight back as the B operand (register r carries k = fg + 4r).
+template <int CB>
+__device__ __forceinline__ void trsm_chunk(double *xs, int sp, int fr, int fg, const double (&lf)[28],
+                                           const double *__restrict__ dinv, double &ss) {
+    constexpr int c0 = 16 * CB;
+    double4_t acc0, acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc0[r] = xs[(c0 + fg + 4 * r) * XS + sp];
+    double dq[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dq[r] = dinv[CB * 256 + fr + 16 * (fg + 4 * r)];
+#pragma unroll
+    for (int q = 0; q < 4 * CB; q += 2) {
+        acc0 = MFMA(-lf[q], xs[(4 * q + fg) * XS + sp], acc0);
+        acc1 = MFMA(-lf[q + 1], xs[(4 * q + 4 + fg) * XS + sp], acc1);
+    }
+    acc0 += acc1;
+    double4_t nw = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) nw = MFMA(dq[r], acc0[r], nw);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        xs[(c0 + fg + 4 * r) * XS + sp] = nw[r];
+        ss = fma(nw[r], nw[r], ss);
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void trsm_panel128_kernel(double *__restrict__ X, int ldx, const double *__restrict__ L, int ldl,
+                                                             const double *__restrict__ dinv, double *__restrict__ sumsq) {
+    extern __shared__ __attribute__((aligned(16))) double xs[];   // NB x XS
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int row0 = blockIdx.x * 64;
+    double *Xg = X + row0;
+    // strip load: 64 rows x 128 columns, 16 B per lane, 8 loads in flight
+    const int li = (tid & 31) * 2, lc = tid >> 5;   // row pair, column (+8 per step)
+#pragma unroll
+    for (int q0 = 0; q0 < 16; q0 += 8) {
+        double2_t v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = *reinterpret_cast<const double2_t *>(Xg + li + (size_t)(lc + 8 * (q0 + q)) * ldx);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) *reinterpret_cast<double2_t *>(xs + (lc + 8 * (q0 + q)) * XS + li) = v[q];
+    }
+    double fa[28], fb[28];
+    trsm_load_frags<1>(L, ldl, fr, fg, fa);
+    __syncthreads();
+    const int sp = wave * 16 + fr;   // this lane's row inside the strip
+    double ss = 0.0;
+    // L fragments of the next chunk are requested before the current chunk's MFMAs (ping-pong fa/fb)
+    trsm_load_frags<2>(L, ldl, fr, fg, fb);
+    trsm_chunk<0>(xs, sp, fr, fg, fa, dinv, ss);
+    trsm_chunk<1>(xs, sp, fr, fg, fa, dinv, ss);
+    trsm_load_frags<3>(L, ldl, fr, fg, fa);
+    trsm_chunk<2>(xs, sp, fr, fg, fb, dinv, ss);
+    trsm_load_frags<4>(L, ldl, fr, fg, fb);
+    trsm_chunk<3>(xs, sp, fr, fg, fa, dinv, ss);
+    trsm_load_frags<5>(L, ldl, fr, fg, fa);
+    trsm_chunk<4>(xs, sp, fr, fg, fb, dinv, ss);
+    trsm_load_frags<6>(L, ldl, fr, fg, fb);
+    trsm_chunk<5>(xs, sp, fr, fg, fa, dinv, ss);
+    trsm_load_frags<7>(L, ldl, fr, fg, fa);
+    trsm_chunk<6>(xs, sp, fr, fg, fb, dinv, ss);
+    trsm_chunk<7>(xs, sp, fr, fg, fa, dinv, ss);
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+        *reinterpret_cast<double2_t *>(Xg + li + (size_t)(lc + 8 * q) * ldx) = *reinterpret_cast<const double2_t *>(xs + (lc + 8 * q) * XS + li);
+    if (sumsq) {
+        ss += __shfl_xor(ss, 16);
+        ss += __shfl_xor(ss, 32);
+        if (fg == 0) sumsq[row0 + sp] += ss;
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// Solve the 128x128 diagonal system in LDS with the tile inverses.  a = L_kk (NB x LS1), v = rhs (NB), in place.
+// trans = 0: L x = b (chunks ascending);  trans = 1: L^T x = b (chunks descending).  128 threads take part.
+__device__ __forceinline__ void diag_solve_lds(const double *a, const double *dv, double *v, double *tmp, int tid, int trans) {
+    for (int s = 0; s < NB / 16; ++s) {
+        const int cb = trans ? (NB / 16 - 1 - s) : s;
+        const int c0 = cb * 16;
+        if (tid < 16) {
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const double m = trans ? dv[cb * 256 + k + 16 * tid] : dv[cb * 256 + tid + 16 * k];
+                acc = fma(m, v[c0 + k], acc);
+            }
+            tmp[tid] = acc;
+        }
+        __syncthreads();
+        if (tid < 16) v[c0 + tid] = tmp[tid];
+        if (tid < NB) {
+            if (!trans && tid >= c0 + 16) {
+                double acc = v[tid];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) acc = fma(-a[tid + (c0 + k) * LS1], tmp[k], acc);
+                v[tid] = acc;
+            } else if (trans && tid < c0) {
+                double acc = v[tid];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) acc = fma(-a[(c0 + k) + tid * LS1], tmp[k], acc);
+                v[tid] = acc;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// forward step k:  x_k = L_kk^-1 t_k  (written to sol);  t[(k+1)*128 + p] -= L21(p,:) x_k  for this workgroup's rows
+__global__ __launch_bounds__(256) void fwd_step_kernel(const double *__restrict__ L, int ldl, const double *__restrict__ dinv,
+                                                       double *__restrict__ t, double *__restrict__ sol, int k0, int r) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double *a = sm, *dv = sm + NB * LS1, *v = dv + 8 * 256, *tmp = v + NB;
+    const int tid = threadIdx.x;
+    const double *Lkk = L + k0 + (size_t)k0 * ldl;
+    load_block_lds<LS1, false>(a, Lkk, ldl, tid);
+    for (int e = tid; e < 8 * 256; e += 256) dv[e] = dinv[e];
+    if (tid < NB) v[tid] = t[k0 + tid];
+    __syncthreads();
+    diag_solve_lds(a, dv, v, tmp, tid, 0);
+    if (blockIdx.x == 0 && tid < NB) sol[k0 + tid] = v[tid];
+    const int p = blockIdx.x * 256 + tid;
+    if (p < r) {
+        const double *Lp = L + (k0 + NB + p) + (size_t)k0 * ldl;
+        double acc = 0.0;
+#pragma unroll 8
+        for (int c = 0; c < NB; ++c) acc = fma(Lp[(size_t)c * ldl], v[c], acc);
+        t[k0 + NB + p] -= acc;
+    }
+}
+
+// backward step k:  x_k = L_kk^-T t_k  (written to sol);  t[c] -= sum_r L(k0+r, c) x_k[r]  for this workgroup's 64 columns c < k0
+__global__ __launch_bounds__(256) void bwd_step_kernel(const double *__restrict__ L, int ldl, const double *__restrict__ dinv,
+                                                       double *__restrict__ t, double *__restrict__ sol, int k0) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double *a = sm, *dv = sm + NB * LS1, *v = dv + 8 * 256, *tmp = v + NB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const double *Lkk = L + k0 + (size_t)k0 * ldl;
+    load_block_lds<LS1, false>(a, Lkk, ldl, tid);
+    for (int e = tid; e < 8 * 256; e += 256) dv[e] = dinv[e];
+    if (tid < NB) v[tid] = t[k0 + tid];
+    __syncthreads();
+    diag_solve_lds(a, dv, v, tmp, tid, 1);
+    if (blockIdx.x == 0 && tid < NB) sol[k0 + tid] = v[tid];
+    const int cbase = blockIdx.x * 64;
+    if (cbase >= k0) return;
+    const double x0 = v[lane], x1 = v[lane + 64];
+    for (int cc = wave; cc < 64; cc += 4) {
+        const int c = cbase + cc;
+        const double *Lc = L + k0 + (size_t)c * ldl;
+        double pr = fma(Lc[lane], x0, Lc[lane + 64] * x1);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) pr += __shfl_xor(pr, o);
+        if (lane == 0) t[c] -= pr;
+    }
+}
+
+// inverses of the 16x16 diagonal tiles of a given lower-triangular L (for callers that bring their own factor)
+__global__ __launch_bounds__(64) void tile_inverse_kernel(const double *__restrict__ L, int ldl, double *__restrict__ dinv) {
+    const int lane = threadIdx.x, fr = lane & 15;
+    const int c0 = blockIdx.x * 16;
+    double row[16], x[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) row[c] = L[(c0 + fr) + (size_t)(c0 + c) * ldl];
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) {
+        double s = (rr == fr) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < rr; ++k) s = fma(-rl64(row[k], rr), x[k], s);
+        x[rr] = s / rl64(row[rr], rr);
+    }
+    if (lane < 16) {
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) dinv[(size_t)blockIdx.x * 256 + rr + 16 * fr] = x[rr];
+    }
+}
+
+}  // namespace
+
+static constexpr int POTRF_LDS = (NB * PLS + 256 + 8) * (int)sizeof(double);
+static constexpr int TRSM_LDS = NB * XS * (int)sizeof(double);
+static constexpr int STEP_LDS = (NB * LS1 + 8 * 256 + NB + 16) * (int)sizeof(double);
+
+int gpk_init_diag_kernels() {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(potrf_diag128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, POTRF_LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(trsm_panel128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, TRSM_LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(fwd_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, STEP_LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(bwd_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, STEP_LDS);
+    return e == hipSuccess ? 0 : 1;
+}
+
+void gpk_potrf_diag128(hipStream_t s, double *A, int lda, double *dinv, int *d_info, int base) {
+    hipLaunchKernelGGL(potrf_diag128_kernel, dim3(1), dim3(256), POTRF_LDS, s, A, lda, dinv, d_info, base);
+}
+void gpk_trsm_panel128(hipStream_t s, double *X, int M, int ldx, const double *Lkk, int ldl, const double *dinv, double *sumsq) {
+    if (M <= 0) return;
+    hipLaunchKernelGGL(trsm_panel128_kernel, dim3(M / 64), dim3(256), TRSM_LDS, s, X, ldx, Lkk, ldl, dinv, sumsq);
+}
+void gpk_fwd_step(hipStream_t s, const double *L, int ldl, const double *dinv_k, double *t, double *sol, int k0, int r) {
+    int grid = r > 0 ? (r + 255) / 256 : 1;
+    hipLaunchKernelGGL(fwd_step_kernel, dim3(grid), dim3(256), STEP_LDS, s, L, ldl, dinv_k, t, sol, k0, r);
+}
+void gpk_bwd_step(hipStream_t s, const double *L, int ldl, const double *dinv_k, double *t, double *sol, int k0) {
+    int grid = k0 > 0 ? k0 / 64 : 1;
+    hipLaunchKernelGGL(bwd_step_kernel, dim3(grid), dim3(256), STEP_LDS, s, L, ldl, dinv_k, t, sol, k0);
+}
+void gpk_tile_inverses(hipStream_t s, const double *L, int np, int ldl, double *dinv) {
+    hipLaunchKernelGGL(tile_inverse_kernel, dim3(np / 16), dim3(64), 0, s, L, ldl, dinv);
+}

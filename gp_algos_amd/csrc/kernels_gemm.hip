@@ -26,13 +26,16 @@ namespace {
 constexpr int TM = 128, TN = 128, TK = GP_BK;
 constexpr int LDS_STRIDE = TM + 16;  // doubles
 
-__device__ __forceinline__ void tile_coords_lower(int t, int &bi, int &bj) {
-    // t = bi*(bi+1)/2 + bj, 0 <= bj <= bi
-    int b = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
-    while (b * (b + 1) / 2 > t) --b;
-    while ((b + 1) * (b + 2) / 2 <= t) ++b;
-    bi = b;
-    bj = t - b * (b + 1) / 2;
+__device__ __forceinline__ void tile_coords_lower(int t, int nbm, int &bi, int &bj) {
+    // lower trapezoid of an (nbm x nbn) tile grid, nbm >= nbn, enumerated column by column:
+    // column bj holds tiles bi = bj .. nbm-1 and starts at S(bj) = bj*nbm - bj*(bj-1)/2.
+    const double c = 2.0 * nbm + 1.0;
+    int b = (int)((c - sqrt(c * c - 8.0 * (double)t)) * 0.5);
+    if (b < 0) b = 0;
+    while (b > 0 && b * nbm - b * (b - 1) / 2 > t) --b;
+    while ((b + 1) * nbm - (b + 1) * b / 2 <= t) ++b;
+    bj = b;
+    bi = b + (t - (b * nbm - b * (b - 1) / 2));
 }
 
 template <int LOWER>
@@ -45,7 +48,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(int M, int N, int K
 
     int bi, bj;
     if (LOWER) {
-        tile_coords_lower(blockIdx.x, bi, bj);
+        tile_coords_lower(blockIdx.x, M / TM, bi, bj);
     } else {
         // XCD-aware: consecutive block ids round-robin over the 8 XCDs; give each XCD a contiguous
         // run of tiles that share the same B panel (bj) so the panel stays in that XCD's L2.
@@ -172,8 +175,8 @@ void gpk_gemm_nt(hipStream_t s, int M, int N, int K, double alpha, const double 
                  double beta, double *C, int ldc, int lower, int ktri) {
     if (M <= 0 || N <= 0) return;
     if (lower) {
-        int nb = M / TM;
-        int ntiles = nb * (nb + 1) / 2;
+        int nbm = M / TM, nbn = N / TN;   // trapezoid: M >= N
+        int ntiles = nbn * nbm - nbn * (nbn - 1) / 2;
         hipLaunchKernelGGL(gemm_nt_f64_kernel<1>, dim3(ntiles), dim3(256), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, ktri);
     } else {
         int ntiles = (M / TM) * (N / TN);

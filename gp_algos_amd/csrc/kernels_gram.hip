@@ -122,6 +122,11 @@ __global__ void copy2d_kernel(double *dst, int ldd, const double *src, int lds, 
     }
 }
 
+__global__ void copy_strided_kernel(double *dst, size_t ds, const double *src, size_t ss, int count) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < count) dst[(size_t)j * ds] = src[(size_t)j * ss];
+}
+
 GramParams make_params(const double *theta, int d, double extra) {
     GramParams p;
     p.sf2 = theta[0] * theta[0];
@@ -164,4 +169,9 @@ void gpk_fill(hipStream_t s, double *p, size_t count, double v) {
 void gpk_copy_2d(hipStream_t s, double *dst, int ldd, const double *src, int lds, int rows, int cols) {
     if (rows <= 0 || cols <= 0) return;
     hipLaunchKernelGGL(copy2d_kernel, dim3(1024), dim3(256), 0, s, dst, ldd, src, lds, rows, cols);
+}
+
+void gpk_copy_strided(hipStream_t s, double *dst, size_t dst_stride, const double *src, size_t src_stride, int count) {
+    if (count <= 0) return;
+    hipLaunchKernelGGL(copy_strided_kernel, dim3((count + 255) / 256), dim3(256), 0, s, dst, dst_stride, src, src_stride, count);
 }

@@ -54,7 +54,7 @@ const char *gp_last_error(const gp_ctx *ctx);
  * while set, every launch of those kernel classes is bracketed by events.  gp_ctx_profile_read
  * returns launches, total ms and the algorithmic work (flops or bytes) the launches of one class
  * carried, then resets that class's counters.  mask = 0 switches profiling off. */
-enum { GP_PROF_OFF = 0, GP_PROF_GEMM = 1, GP_PROF_SYRK = 2, GP_PROF_GRAM = 3, GP_PROF_TRSM = 4, GP_PROF_POTRF_DIAG = 5, GP_PROF_NCLASSES = 6 };
+enum { GP_PROF_OFF = 0, GP_PROF_GEMM = 1, GP_PROF_SYRK = 2, GP_PROF_GRAM = 3, GP_PROF_TRSM = 4, GP_PROF_POTRF_DIAG = 5, GP_PROF_PANEL_UPD = 6, GP_PROF_NCLASSES = 7 };
 gp_status gp_ctx_profile(gp_ctx *ctx, int mask);
 gp_status gp_ctx_profile_read(gp_ctx *ctx, int which, int64_t *launches, double *total_ms, double *work);
 /* fp64 MFMA peak probe: runs a register-only v_mfma_f64_16x16x4_f64 loop on every CU and returns

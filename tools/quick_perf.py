@@ -43,8 +43,8 @@ print("refit n=%d: %.3f ms  -> cholesky-equivalent %.2f TFLOP/s (n^3/3 over whol
 ctx.check(lib.gp_predict_dev(h, dXs, m, m, dmean, dvar))
 tp = timed(lambda: ctx.check(lib.gp_predict_dev(h, dXs, m, m, dmean, dvar)), reps=2)
 print("predict m=%d: %.3f ms -> %.1f points/s, %.2f TFLOP/s (n^2 m)" % (m, tp * 1e3, m / tp, n * n * m / tp / 1e12), flush=True)
-names = {1: "gemm", 2: "syrk", 3: "gram", 4: "trsm_panel", 5: "potrf_diag"}
-for cls in (5, 4, 2, 3):
+names = {1: "gemm", 2: "syrk", 3: "gram", 4: "trsm_panel", 5: "potrf_diag", 6: "panel_upd"}
+for cls in (5, 4, 6, 2, 3):
     ctx.profile(1 << cls)
     ctx.check(lib.gp_model_refit_dev(h, L.dptr(theta), float("nan")))
     k, ms, work = ctx.profile_read(cls)
