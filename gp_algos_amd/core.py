@@ -201,3 +201,53 @@ class RegressionModel:
         self.ctx.check(self.ctx._lib.gp_predict(self.h, L.dptr(Xs), m, max(m, 1), L.dptr(mean), L.dptr(var),
                                                 L.dptr(cov) if full_cov else None, max(m, 1)))
         return mean, var, cov
+
+
+class EpClassifierState:
+    """EpParameterEstimator state on the GPU: K, Sigma, L and the site parameters."""
+
+    def __init__(self, ctx, K, y):
+        self.ctx = ctx
+        K = L.f64(K)
+        y = np.ascontiguousarray(y, dtype=np.int32)
+        self.n = K.shape[0]
+        if K.shape[1] != self.n or y.size != self.n:
+            raise ValueError("kernelMatrix.rows must equal targets.length")
+        h = C.c_void_p()
+        st = ctx._lib.gp_ep_create(ctx.h, L.dptr(K), self.n, self.n, y.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(h))
+        ctx.check(st)
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None) and getattr(self.ctx, "h", None):
+            self.ctx._lib.gp_ep_destroy(self.h)
+        self.h = None
+
+    __del__ = close
+
+    def sweep(self, nsweeps=1):
+        tau, nu = np.zeros(self.n), np.zeros(self.n)
+        info = C.c_int()
+        st = self.ctx._lib.gp_ep_sweep(self.h, int(nsweeps), L.dptr(tau), L.dptr(nu), C.byref(info))
+        self.ctx.check(st, info.value)
+        return tau, nu
+
+    def lml(self, strict=True):
+        v = C.c_double()
+        self.ctx.check(self.ctx._lib.gp_ep_lml(self.h, int(bool(strict)), C.byref(v)))
+        return v.value
+
+    def get(self, what):
+        mat = what in (L.GP_EP_GET_L, L.GP_EP_GET_SIGMA)
+        out = np.zeros((self.n, self.n), order="F") if mat else np.zeros(self.n)
+        self.ctx.check(self.ctx._lib.gp_ep_get(self.h, what, L.dptr(out), self.n))
+        return out
+
+    def predict(self, Ks, kss_diag):
+        Ks, kd = L.f64(Ks), L.f64(kss_diag)
+        m = Ks.shape[0]
+        if Ks.shape[1] != self.n or kd.size != m:
+            raise ValueError("dimension mismatch")
+        prob = np.zeros(m)
+        self.ctx.check(self.ctx._lib.gp_ep_predict(self.h, L.dptr(Ks), m, max(m, 1), L.dptr(kd), L.dptr(prob)))
+        return prob

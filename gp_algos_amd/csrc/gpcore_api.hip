@@ -28,7 +28,7 @@ void gp_prof_end(gp_ctx *ctx, int cls, double work, hipStream_t s) {
 namespace {
 
 struct ws_slot { void *p = nullptr; size_t bytes = 0; };
-enum { WS_VT = 0, WS_PARTIAL, WS_SUMSQ, WS_A, WS_B, WS_C, WS_D, WS_E, WS_COUNT };
+
 struct ctx_ext { ws_slot ws[WS_COUNT]; };
 
 // gp_ctx owns a ctx_ext through this side table (keeps the header struct POD-ish)
@@ -219,6 +219,20 @@ void model_factor(gp_model *m) {
 }
 
 }  // namespace
+
+// external-linkage shims for the other host translation units (gpcore_ep.hip)
+gp_status gpi_ws_get(gp_ctx *ctx, int slot, size_t bytes, double **out) { return ws_get(ctx, slot, bytes, out); }
+gp_status gpi_upload_2d(gp_ctx *ctx, double *dst, int ldd, const double *src, int lds, int rows, int cols) { return upload_2d(ctx, dst, ldd, src, lds, rows, cols); }
+gp_status gpi_download_2d(gp_ctx *ctx, double *dst, int ldd, const double *src, int lds, int rows, int cols) { return download_2d(ctx, dst, ldd, src, lds, rows, cols); }
+gp_status gpi_read_info(gp_ctx *ctx, int *info) { return read_info(ctx, info); }
+void gpi_chol_blocked(gp_ctx *ctx, double *A, int np, int lda, double *dinv, int extra) { chol_blocked(ctx, A, np, lda, dinv, extra); }
+void gpi_solve_rows_lower(gp_ctx *ctx, double *Vt, int mp, const double *L, int np, int ldl, const double *dinv, double *sumsq) { solve_rows_lower(ctx, Vt, mp, L, np, ldl, dinv, sumsq); }
+void gpi_back_solve_vec(gp_ctx *ctx, const double *L, int np, int ldl, const double *dinv, double *z, double *alpha) { back_solve_vec(ctx, L, np, ldl, dinv, z, alpha); }
+// z <- L^-1 t (t is consumed): one fused launch per block step
+void gpi_forward_solve_vec(gp_ctx *ctx, const double *L, int np, int ldl, const double *dinv, double *t, double *z) {
+    for (int k = 0; k < np / GP_NB; ++k)
+        gpk_fwd_step(ctx->stream, L, ldl, dinv + (size_t)k * GP_NB * 16, t, z, k * GP_NB, np - (k + 1) * GP_NB);
+}
 
 extern "C" {
 

@@ -117,3 +117,14 @@ void gpk_bwd_step(hipStream_t s, const double *L, int ldl, const double *dinv_k,
 void gpk_tile_inverses(hipStream_t s, const double *L, int np, int ldl, double *dinv);
 // dst[j*dst_stride] = src[j*src_stride], j < count
 void gpk_copy_strided(hipStream_t s, double *dst, size_t dst_stride, const double *src, size_t src_stride, int count);
+
+// ---- host-side helpers shared between translation units (defined in gpcore_api.hip) ----
+enum { WS_VT = 0, WS_PARTIAL, WS_SUMSQ, WS_A, WS_B, WS_C, WS_D, WS_E, WS_COUNT };
+gp_status gpi_ws_get(gp_ctx *ctx, int slot, size_t bytes, double **out);
+gp_status gpi_upload_2d(gp_ctx *ctx, double *dst, int ldd, const double *src, int lds, int rows, int cols);
+gp_status gpi_download_2d(gp_ctx *ctx, double *dst, int ldd, const double *src, int lds, int rows, int cols);
+gp_status gpi_read_info(gp_ctx *ctx, int *info);
+void gpi_chol_blocked(gp_ctx *ctx, double *A, int np, int lda, double *dinv, int extra);
+void gpi_solve_rows_lower(gp_ctx *ctx, double *Vt, int mp, const double *L, int np, int ldl, const double *dinv, double *sumsq);
+void gpi_back_solve_vec(gp_ctx *ctx, const double *L, int np, int ldl, const double *dinv, double *z, double *alpha);
+void gpi_forward_solve_vec(gp_ctx *ctx, const double *L, int np, int ldl, const double *dinv, double *t, double *z);

@@ -253,3 +253,85 @@ def test_lml_grad_flags_non_pd_setting(ctx):
     lml, grad, info = ctx.lml_grad_batched(Xdup, y, np.stack([p["theta"], bad]))
     assert info[0] == 0 and np.isfinite(lml[0])
     assert info[1] > 0 and np.isnan(lml[1])
+
+
+# ---- EP binary classification (EpParameterEstimator / GpClassifier) -----------------------------
+TOL_EP = 1e-8        # relative, site parameters after a fixed number of sweeps
+TOL_PROB = 1e-9      # absolute, class-1 probabilities
+
+
+def _ep_problem(n, d=3, seed=7, sf=1.6, ell=1.2):
+    p = synth.regression(n, d, 0, seed, seed + 1, 0, np.concatenate(([sf], ell * np.ones(d), [0.0])))
+    f = p["X"].sum(axis=1) / np.sqrt(d) + 0.3 * synth.normal(seed + 5, np.arange(n))
+    y = np.where(f >= 0.0, 1, -1).astype(np.int32)
+    K = orc.gram_sym(p["X"], p["theta"])
+    return p, K, y
+
+
+@pytest.mark.parametrize("n,sweeps", [(5, 2), (60, 3), (128, 2), (200, 3), (300, 2)])
+def test_ep_sweeps_vs_oracle(ctx, n, sweeps):
+    from gp_algos_amd import _lib as L
+    from gp_algos_amd.core import EpClassifierState
+    p, K, y = _ep_problem(n, seed=n)
+    ep = EpClassifierState(ctx, K, y)
+    tau, nu = ep.sweep(sweeps)
+    o = orc.ep_estimate(K, y, sweeps)
+    assert o["sweeps"] == sweeps
+    assert np.max(np.abs(tau - o["tau"])) <= TOL_EP * np.max(np.abs(o["tau"]))
+    assert np.max(np.abs(nu - o["nu"])) <= TOL_EP * np.max(np.abs(o["nu"]))
+    assert np.max(np.abs(ep.get(L.GP_EP_GET_MU) - o["mu"])) <= TOL_EP * np.max(np.abs(o["mu"]))
+    assert np.max(np.abs(ep.get(L.GP_EP_GET_SIGMA) - o["Sigma"])) <= TOL_EP * np.max(np.abs(o["Sigma"]))
+    assert np.max(np.abs(ep.get(L.GP_EP_GET_CAV_TAU) - o["cav_tau"])) <= TOL_EP * np.max(np.abs(o["cav_tau"]))
+    Lg = ep.get(L.GP_EP_GET_L)
+    assert np.all(np.triu(Lg, 1) == 0.0)
+    assert np.max(np.abs(Lg - o["L"])) <= TOL_EP * np.max(np.abs(o["L"]))
+    # EP log marginal likelihood: as compiled (strict) and as intended (corrected)
+    for strict in (True, False):
+        ol = orc.ep_lml(o, y, strict=strict)
+        assert abs(ep.lml(strict=strict) - ol) <= 1e-9 * max(1.0, abs(ol))
+    ep.close()
+
+
+def test_ep_sweeps_one_at_a_time_equal_batched(ctx):
+    from gp_algos_amd.core import EpClassifierState
+    _, K, y = _ep_problem(150, seed=3)
+    a = EpClassifierState(ctx, K, y)
+    b = EpClassifierState(ctx, K, y)
+    ta, na = a.sweep(3)
+    for _ in range(3):
+        tb, nb = b.sweep(1)
+    assert np.array_equal(ta, tb) and np.array_equal(na, nb)     # same kernels, same order: bit-identical
+    a.close()
+    b.close()
+
+
+@pytest.mark.parametrize("n,m", [(60, 7), (200, 130)])
+def test_ep_classify_vs_oracle(ctx, n, m):
+    from gp_algos_amd.core import EpClassifierState
+    p, K, y = _ep_problem(n, seed=n + 1)
+    Xs = synth._xmat(99, m, 3, -2.0, 4.0)
+    Ks = orc.gram_cross(Xs, p["X"], p["theta"])
+    kss = np.full(m, p["theta"][0] ** 2 + p["theta"][-1] ** 2)
+    ep = EpClassifierState(ctx, K, y)
+    tau, nu = ep.sweep(3)
+    prob = ep.predict(Ks, kss)
+    o = orc.ep_estimate(K, y, 3)
+    oprob, _, _ = orc.ep_classify(K, o["L"], o["tau"], o["nu"], Ks, kss)
+    assert np.max(np.abs(prob - oprob)) <= TOL_PROB
+    assert np.all((prob >= 0.0) & (prob <= 1.0))
+    ep.close()
+
+
+def test_ep_argument_errors(ctx):
+    from gp_algos_amd.core import EpClassifierState
+    _, K, y = _ep_problem(10)
+    with pytest.raises(ValueError):
+        EpClassifierState(ctx, K, y[:-1])             # require(kernelMatrix.rows == targets.length)
+    bad = y.copy()
+    bad[0] = 0
+    with pytest.raises(ValueError):
+        EpClassifierState(ctx, K, bad)                # targets must contain values from set {-1,1}
+    ep = EpClassifierState(ctx, K, y)
+    with pytest.raises(ValueError):
+        ep.predict(np.zeros((2, 10)), np.ones(2))     # classify before trainClassifier
+    ep.close()
