@@ -52,6 +52,7 @@ SIGNATURES = {
     "gp_lml_grad_rbf_batched": (_i, [_vp, _dp, _i, _i, _i, _dp, _dp, _i, _i, _d, _dp, _dp, _ip]),
     "gp_ep_create": (_i, [_vp, _dp, _i, _i, C.POINTER(C.c_int32), C.POINTER(_vp)]),
     "gp_ep_sweep": (_i, [_vp, _i, _dp, _dp, _ip]),
+    "gp_ep_set_site_params": (_i, [_vp, _dp, _dp, _ip]),
     "gp_ep_lml": (_i, [_vp, _i, _dp]),
     "gp_ep_get": (_i, [_vp, _i, _dp, _i]),
     "gp_ep_predict": (_i, [_vp, _dp, _i, _i, _dp, _dp]),

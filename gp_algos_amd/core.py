@@ -232,6 +232,14 @@ class EpClassifierState:
         self.ctx.check(st, info.value)
         return tau, nu
 
+    def load_site_params(self, tau, nu):
+        tau, nu = L.f64(tau), L.f64(nu)
+        if tau.size != self.n or nu.size != self.n:
+            raise ValueError("site parameter length mismatch")
+        info = C.c_int()
+        st = self.ctx._lib.gp_ep_set_site_params(self.h, L.dptr(tau), L.dptr(nu), C.byref(info))
+        self.ctx.check(st, info.value)
+
     def lml(self, strict=True):
         v = C.c_double()
         self.ctx.check(self.ctx._lib.gp_ep_lml(self.h, int(bool(strict)), C.byref(v)))

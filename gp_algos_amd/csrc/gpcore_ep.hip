@@ -291,6 +291,24 @@ gp_status gp_ep_sweep(gp_ep *ep, int nsweeps, double *tau, double *nu, int *info
     return GP_OK;
 }
 
+gp_status gp_ep_set_site_params(gp_ep *ep, const double *tau, const double *nu, int *info) {
+    if (!ep) return GP_EINVAL;
+    gp_ctx *ctx = ep->ctx;
+    GP_REQUIRE(ctx, tau && nu, "null pointer");
+    GP_HIP(ctx, hipSetDevice(ctx->device));
+    if (info) *info = 0;
+    GP_HIP(ctx, hipMemsetAsync(ctx->d_info, 0, sizeof(int), ctx->stream));
+    GP_TRY(gpi_upload_2d(ctx, ep->tau(), ep->np, tau, ep->n, ep->n, 1));
+    GP_TRY(gpi_upload_2d(ctx, ep->nu(), ep->np, nu, ep->n, ep->n, 1));
+    GP_TRY(ep_refactor(ep));
+    int h = 0;
+    GP_TRY(gpi_read_info(ctx, &h));
+    if (info) *info = h;
+    if (h) { GP_SET_ERR(ctx, "I + S^1/2 K S^1/2 not positive definite at pivot %d", h); return GP_ENOTPD; }
+    if (ep->sweeps == 0) ep->sweeps = 1;
+    return GP_OK;
+}
+
 gp_status gp_ep_lml(gp_ep *ep, int strict, double *lml) {
     if (!ep || !lml) return GP_EINVAL;
     gp_ctx *ctx = ep->ctx;

@@ -1,0 +1,147 @@
+"""Mirror of gp/regression/GpPredictor.scala on top of libgpcore.so.
+
+class GpPredictor(kernelFunc) keeps the reference's method names, argument meaning, return tuples and
+error behaviour; the bodies call the C-ABI (Gram + blocked Cholesky + triangular solves on the GPU).
+GaussianRbfKernel goes through the fused device path; any other KernelFunc falls back to a HOST-BUILT
+Gram matrix (the reference's own per-pair loop) that is then factored on the GPU."""
+import math
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+
+from ... import default_context
+from ...core import RegressionModel
+from ...optimization.optimization import BreezeLbfgsOptimizer
+from ...utils import matrix_utils
+from ...utils.kernel_requisites import GaussianRbfKernel
+from ...utils.stats_utils import GaussianDistribution
+
+
+@dataclass
+class PredictionInput:   # GpPredictor.scala:162-169
+    trainingData: np.ndarray
+    testData: np.ndarray
+    sigmaNoise: Optional[float]
+    targets: np.ndarray
+
+    def toPredictionTrainingInput(self):
+        return PredictionTrainingInput(self.trainingData, self.sigmaNoise, self.targets)
+
+
+@dataclass
+class PredictionTrainingInput:   # :171-172
+    trainingData: np.ndarray
+    sigmaNoise: Optional[float]
+    targets: np.ndarray
+
+
+class GpPredictor:
+    def __init__(self, kernelFunc):
+        self.kernelFunc = kernelFunc
+
+    # -- internal: fitted device model for (X, y, hyperParams) ----------------------------------
+    def _fit(self, trainingData, hyperParams, sigmaNoise, targets):
+        X = np.asfortranarray(np.asarray(trainingData, dtype=np.float64))
+        y = np.asarray(targets, dtype=np.float64).reshape(-1)
+        if X.shape[0] != y.size:   # require(...) :108-109
+            raise ValueError("requirement failed: Number of objects in training data matrix should be equal to targets vector length")
+        kf = self.kernelFunc.changeHyperParams(hyperParams.toDenseVector())
+        ctx = default_context()
+        if isinstance(kf, GaussianRbfKernel):
+            return kf, RegressionModel(ctx, X, y, kf.rbfParams.toDenseVector(), sigma_noise=sigmaNoise)
+        K = matrix_utils.buildKernelMatrix(kf, X)
+        if sigmaNoise is not None:
+            K = K + np.eye(X.shape[0]) * sigmaNoise   # un-squared, :116
+        return kf, RegressionModel(ctx, y=y, gram=K)
+
+    def preComputeComponents(self, trainingData, *args):
+        """preComputeComponents(trainingData, sigmaNoise, targets)                :89-94
+           preComputeComponents(trainingData, hyperParams, sigmaNoise, targets)   :104-124
+           -> afterLearningComponents = (L, alphaVec, Option[noise * I])          :157"""
+        if len(args) == 2:
+            hyperParams, (sigmaNoise, targets) = self.kernelFunc.hyperParams, args
+        else:
+            hyperParams, sigmaNoise, targets = args
+        _, mdl = self._fit(trainingData, hyperParams, sigmaNoise, targets)
+        try:
+            L, alpha = mdl.L(), mdl.alpha()
+        finally:
+            mdl.close()
+        n = L.shape[0]
+        return L, alpha, (np.eye(n) * sigmaNoise if sigmaNoise is not None else None)
+
+    def predict(self, input, hyperParams=None):   # :24-43
+        hyperParams = self.kernelFunc.hyperParams if hyperParams is None else hyperParams
+        kf, mdl = self._fit(input.trainingData, hyperParams, input.sigmaNoise, input.targets)
+        try:
+            Xs = np.asfortranarray(np.asarray(input.testData, dtype=np.float64))
+            if isinstance(kf, GaussianRbfKernel):
+                mean, _, cov = mdl.predict(Xs, full_cov=True)
+            else:
+                mean, cov = self._posterior_from_host_gram(kf, input.trainingData, Xs, mdl.L(), mdl.alpha())
+            if input.sigmaNoise is not None:
+                # fVariance + noiseDiagMtx.get (:37-39): an n x n matrix added to an m x m one -- only defined for m == n
+                if cov.shape[0] != mdl.n:
+                    raise ValueError("requirement failed: Dimension mismatch! (noiseDiagMtx is n x n, fVariance is m x m)")
+                cov = cov + np.eye(mdl.n) * input.sigmaNoise
+            return GaussianDistribution(mean=mean, sigma=cov), mdl.lml()
+        finally:
+            mdl.close()
+
+    def computePosterior(self, trainingData, testData, l, alphaVec, kernelFunc=None):   # :45-58
+        kf = self.kernelFunc if kernelFunc is None else kernelFunc
+        Xs = np.asfortranarray(np.asarray(testData, dtype=np.float64))
+        Ks = matrix_utils.buildKernelMatrix(kf, Xs, trainingData)
+        fMean = Ks @ np.asarray(alphaVec, dtype=np.float64)
+        vMatrix = matrix_utils.forwardSolve(l, np.asfortranarray(Ks.T))
+        fVariance = matrix_utils.buildKernelMatrix(kf, Xs) - vMatrix.T @ vMatrix
+        return GaussianDistribution(mean=fMean, sigma=fVariance), vMatrix
+
+    def _posterior_from_host_gram(self, kf, trainingData, Xs, L, alpha):
+        dist, _ = self.computePosterior(trainingData, Xs, L, alpha, kf)
+        return dist.mean, dist.sigma
+
+    def logLikelihoodWithDerivatives(self, input, hyperParams, optimizedParamsNum):   # :60-80
+        kf = self.kernelFunc.changeHyperParams(hyperParams.toDenseVector())
+        if not isinstance(kf, GaussianRbfKernel):
+            raise NotImplementedError("device LML gradient is implemented for GaussianRbfKernel")
+        X = np.asfortranarray(np.asarray(input.trainingData, dtype=np.float64))
+        lml, grad, info = default_context().lml_grad_batched(X, input.targets, kf.rbfParams.toDenseVector()[None, :],
+                                                             nparams=optimizedParamsNum, sigma_noise=input.sigmaNoise)
+        if info[0]:
+            from ..._lib import NotPositiveDefinite
+            raise NotPositiveDefinite(2, "matrix not positive definite at pivot %d" % info[0], int(info[0]))
+        return float(lml[0]), grad[0].copy()
+
+    def obtainOptimalHyperParams(self, trainingData, sigmaNoise, targets, optimizeNoise):   # :126-142
+        optimizer = BreezeLbfgsOptimizer(maxIter=20)
+        full = self.kernelFunc.hyperParams.toDenseVector()
+        init = full if optimizeNoise else full[:-1]
+
+        def objective(params):
+            hp = self.kernelFunc.hyperParams.fromDenseVector(params)   # require(dv.length == d+2) :55 -- the
+            # reference fails here when optimizeNoise = false; kept as is.
+            ti = PredictionTrainingInput(trainingData, sigmaNoise, targets)
+            return self.logLikelihoodWithDerivatives(ti, hp, len(params))
+
+        best = optimizer.maximize(objective, init)
+        return self.kernelFunc.hyperParams.fromDenseVector(best)
+
+    def predictWithParamsOptimization(self, input, optimizeNoise):   # :82-87
+        hp = self.obtainOptimalHyperParams(input.trainingData, input.sigmaNoise, input.targets, optimizeNoise)
+        dist, ll = self.predict(input, hyperParams=hp)
+        return dist, ll, hp
+
+    def preComputeComponentsWithHpOptimization(self, trainingData, sigmaNoise, targets):   # :96-101
+        hp = self.obtainOptimalHyperParams(trainingData, sigmaNoise, targets, True)
+        return self.preComputeComponents(trainingData, hp, sigmaNoise, targets), hp
+
+    @staticmethod
+    def logLikelihood(alphaVector, L, targets):   # :144-149 (host form, for callers that already hold L and alpha)
+        n = L.shape[0]
+        a1 = -0.5 * float(np.dot(targets, alphaVector))
+        a2 = 0.0
+        for i in range(n):
+            a2 = a2 + math.log(L[i, i])
+        return a1 - a2 - 0.5 * n * math.log(2 * math.pi)

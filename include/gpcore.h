@@ -101,7 +101,7 @@ gp_status gp_inv_lower(gp_ctx *ctx, const double *L, int n, int ldl, double *Lin
 gp_status gp_fit_rbf(gp_ctx *ctx, const double *X, int n, int d, int ldx, const double *y, const double *theta, double sigma_noise, gp_model **out, int *info);
 gp_status gp_fit_rbf_dev(gp_ctx *ctx, const double *dX, int n, int d, int ldx, const double *dy, const double *theta, double sigma_noise, gp_model **out, int *info);
 /* Same with a host-built Gram matrix (any KernelFunc, e.g. Co2Kernel gp/regression/Co2Prediction.scala:29).
- * Such a model supports gp_model_get and gp_predict_from_cross only. */
+ * Such a model supports gp_model_get only (the caller forms K* itself and solves with gp_trsm_lower). */
 gp_status gp_fit_from_gram(gp_ctx *ctx, const double *K, int n, int ldk, const double *y, gp_model **out, int *info);
 /* Re-fit an existing model in place (same n, d): no allocation, fully asynchronous. */
 gp_status gp_model_refit_dev(gp_model *model, const double *theta, double sigma_noise);
@@ -133,6 +133,9 @@ gp_status gp_ep_create(gp_ctx *ctx, const double *K, int n, int ldk, const int32
 /* nsweeps sweeps of estimateSiteParams :40-62 (site loop + end-of-sweep refactorisation).
  * tau[n], nu[n] receive the site parameters after the last sweep (either may be NULL). */
 gp_status gp_ep_sweep(gp_ep *ep, int nsweeps, double *tau, double *nu, int *info);
+/* Load site parameters obtained earlier (GpClassifier.classify with learnParams = Some(..), GpClassifier.scala:26-28):
+ * rebuilds L, Sigma and mu from them with one end-of-sweep refactorisation (EpParameterEstimator.scala:56-61). */
+gp_status gp_ep_set_site_params(gp_ep *ep, const double *tau, const double *nu, int *info);
 /* epMarginalLikelihood :71-96.  strict != 0: as compiled (term at :92 dropped); 0: intended formula. */
 gp_status gp_ep_lml(gp_ep *ep, int strict, double *lml);
 enum { GP_EP_GET_L = 0, GP_EP_GET_SIGMA = 1, GP_EP_GET_MU = 2, GP_EP_GET_CAV_TAU = 3, GP_EP_GET_CAV_NU = 4 };
