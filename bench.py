@@ -47,6 +47,78 @@ def cpu_baseline(p, L_host, alpha_host, budget_pts):
                        "(oracle dpotf2 at n=%d is minutes)" % (k, p["Xs"].shape[0], p["X"].shape[0], p["X"].shape[0])), mean, var, k
 
 
+def run_secondary(args):
+    """Secondary workloads (not the headline metric): C3 batched LML+gradient sharded over ranks, C4 EP sweeps."""
+    import torch
+    from gp_algos_amd import dist as gdist
+    rank, local_rank, world = gdist.env_rank_world()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    gdist.init("nccl", torch.device("cuda", local_rank))
+    import __graft_entry__ as entry
+    entry.build()
+    from gp_algos_amd import _lib as L, synth
+    from gp_algos_amd.core import Context, EpClassifierState
+    ctx = Context(local_rank)
+
+    def fence():
+        ctx.sync()
+        torch.cuda.synchronize()
+        gdist.barrier()
+        torch.cuda.synchronize()
+
+    if args.workload == "c3":
+        n = args.n if args.n != 8192 else 4096
+        p = synth.config_c3(n, args.d)
+        B = p["thetas"].shape[0]
+        lo, hi = gdist.shard_range(B, rank, world)
+        mine = p["thetas"][lo:hi]
+        for _ in range(args.warmup):
+            ctx.lml_grad_batched(p["X"], p["y"], mine[:1])
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            lml, grad, info = ctx.lml_grad_batched(p["X"], p["y"], mine)
+        fence()
+        dt = gdist.max_over_ranks(time.perf_counter() - t0, device="cuda")
+        if rank == 0:
+            flops = (n ** 3) * (1 / 3 + 1 / 2 + 1 / 3) + 2.0 * (args.d + 2) * n * n
+            print(json.dumps({"metric": "LML+gradient settings/sec at n=%d fp64, P=%d" % (n, args.d + 2), "value": B * args.steps / dt,
+                              "unit": "settings/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                              "dtype": "f64", "data": "synthetic",
+                              "config": {"workload": "C3: log-marginal-likelihood + gradient over %d hyper-parameter settings, n=%d d=%d, "
+                                                     "settings sharded %d per GPU" % (B, n, args.d, hi - lo), "B": B, "n": n},
+                              "approx_tflops_per_gpu": flops * (hi - lo) * args.steps / dt / 1e12,
+                              "lml_first": float(lml[0]), "all_pd": bool(np.all(info == 0))}), flush=True)
+    else:
+        n = args.n if args.n != 8192 else 4096
+        sweeps = 50
+        p = synth.config_c4(n, args.d)
+        K = ctx.gram_rbf(p["X"], p["theta"], full=True)
+        ep = EpClassifierState(ctx, K, p["y"])
+        ep.sweep(1)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            tau, nu = ep.sweep(sweeps)
+        fence()
+        dt = gdist.max_over_ranks(time.perf_counter() - t0, device="cuda")
+        if rank == 0:
+            print(json.dumps({"metric": "EP sweeps/sec at n=%d fp64" % n, "value": world * sweeps * args.steps / dt, "unit": "sweeps/s",
+                              "n_gpus": world, "steps": args.steps, "warmup": 1, "ms_per_step": dt / args.steps * 1e3,
+                              "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                              "config": {"workload": "C4: GP binary classification via EP, n=%d, %d sweeps per step (replicas only: one EP run "
+                                                     "does not shard)" % (n, sweeps), "n": n, "sweeps": sweeps},
+                              "algorithmic_tflops": (13.0 / 3.0) * n ** 3 * sweeps * args.steps / dt / 1e12,
+                              "ep_lml_strict": ep.lml(True), "ep_lml_corrected": ep.lml(False),
+                              "tau_range": [float(tau.min()), float(tau.max())]}), flush=True)
+        ep.close()
+    ctx.close()
+    gdist.barrier()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -56,7 +128,12 @@ def main():
     ap.add_argument("--d", type=int, default=8)
     ap.add_argument("--m", type=int, default=65536)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4"],
+                    help="c2 (default, the BASELINE.json metric): fit + posterior; c3: batched LML+gradient over 64 settings; "
+                         "c4: EP classification sweeps")
     args = ap.parse_args()
+    if args.workload != "c2":
+        return run_secondary(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

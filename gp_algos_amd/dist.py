@@ -1,0 +1,87 @@
+"""Multi-GPU driver logic: one process per GPU, the path shards over INDEPENDENT units (test points, hyper-parameter
+settings), no data-path collective.  torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the
+CPU tests) is used for rendezvous, barriers, a max-reduce of timings and one small all_gather of results.
+
+Partitioning follows SURVEY.md 8(e): setting index b -> rank b // ceil(B / G); test points sliced contiguously."""
+import os
+
+import numpy as np
+
+
+def env_rank_world():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def shard_range(total, rank, world):
+    """Contiguous slice [lo, hi) of `total` units owned by `rank`; sizes differ by at most one chunk at the tail."""
+    per = -(-total // world)
+    lo = min(total, rank * per)
+    return lo, min(total, lo + per)
+
+
+def owner_of(index, total, world):
+    return index // (-(-total // world))
+
+
+def init(backend, device=None):
+    import torch.distributed as dist
+    rank, local_rank, world = env_rank_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        kw = {}
+        if backend == "nccl" and device is not None:
+            kw["device_id"] = device
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return rank, local_rank, world
+
+
+def barrier():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+
+
+def max_over_ranks(value, device="cpu"):
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def all_gather_rows(local, total_rows, device="cpu"):
+    """Assemble per-rank result rows (each rank holds the rows of shard_range(total_rows, rank, world)) on every rank.
+    Message size is tiny (B x (1+P) doubles), one collective."""
+    import torch
+    import torch.distributed as dist
+    local = np.ascontiguousarray(np.atleast_2d(local), dtype=np.float64)
+    if not (dist.is_available() and dist.is_initialized()):
+        return local
+    world = dist.get_world_size()
+    per = -(-total_rows // world)
+    pad = np.full((per, local.shape[1]), np.nan)
+    pad[:local.shape[0]] = local
+    mine = torch.from_numpy(pad).to(device)
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine)
+    full = np.concatenate([p.cpu().numpy() for p in parts], axis=0)
+    return full[:total_rows]
+
+
+def lml_grad_sharded(evaluate, thetas, device="cpu"):
+    """Batched LML + gradient over B settings, sharded setting-wise.  `evaluate(thetas_slice) -> (lml[b], grad[b, P])`
+    runs on this rank's GPU (Context.lml_grad_batched); returns the assembled (lml[B], grad[B, P]) on every rank."""
+    rank, _, world = env_rank_world()
+    thetas = np.ascontiguousarray(np.atleast_2d(thetas), dtype=np.float64)
+    B = thetas.shape[0]
+    lo, hi = shard_range(B, rank, world)
+    if hi > lo:
+        lml, grad = evaluate(thetas[lo:hi])
+        local = np.concatenate([np.asarray(lml).reshape(-1, 1), np.atleast_2d(grad)], axis=1)
+    else:
+        local = np.zeros((0, 1 + thetas.shape[1]))
+    full = all_gather_rows(local, B, device=device)
+    return full[:, 0].copy(), full[:, 1:].copy()
