@@ -214,6 +214,16 @@ def main():
 
     out = None
     if rank == 0:
+        # HBM traffic per launch of the dominant kernel: PMC counters cannot be read from inside the process, so the
+        # figure comes from the committed rocprofv3 --pmc passes of this same command (profiles/, FETCH_SIZE doubled
+        # per the gfx950 correction); only reported for the configuration those passes ran.
+        traffic = None
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_b_pmc_c2_summary.json")))
+            if (n, d, m) == (8192, 8, 65536):
+                traffic = pm["kernels"]["gemm_nt_f64_kernel<0>"]["hbm_bytes_per_launch_corrected"]
+        except Exception:
+            traffic = None
         ms_per_step = dt / args.steps * 1e3
         value = world * m * args.steps / dt
         gemm_tflops = g_work / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
@@ -228,7 +238,9 @@ def main():
                        "parallelism": "test points sharded %d-way, model refit per rank, no data-path collective" % world},
             "roofline": {"kernel": "gemm_nt_f64_kernel<0> (posterior solve Vt_i -= Vt_<i L_i,<i^T, v_mfma_f64_16x16x4_f64)",
                          "bound": "mfma", "achieved": gemm_tflops, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": gemm_tflops / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
+                         "frac": gemm_tflops / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic,
+                         "traffic_unit": "HBM bytes per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_b_pmc_c2_summary.json)",
+                         "algorithmic_bytes_per_launch": 8.0 * (m * (n / 2.0) + 128 * (n / 2.0) + 2.0 * m * 128),
                          "launches": g_k, "avg_launch_us": g_ms / max(g_k, 1) * 1e3,
                          "flops_per_launch_avg": g_work / max(g_k, 1)},
             "cholesky": {"fit_ms": t_fit * 1e3, "total_tflops": (n ** 3 / 3.0) / t_fit / 1e12,

@@ -58,6 +58,11 @@ class Context:
         self.check(self._lib.gp_probe_mfma_f64(self.h, C.byref(v)))
         return v.value
 
+    def probe_mfma_f64_ex(self, waves_per_simd=1):
+        v, clk, cyc = C.c_double(), C.c_double(), C.c_double()
+        self.check(self._lib.gp_probe_mfma_f64_ex(self.h, waves_per_simd, C.byref(v), C.byref(clk), C.byref(cyc)))
+        return dict(tflops=v.value, clock_mhz=clk.value, cycles_per_mfma=cyc.value)
+
     # -- raw device memory --------------------------------------------------------------------
     def dev_alloc(self, nbytes):
         p = C.c_void_p()

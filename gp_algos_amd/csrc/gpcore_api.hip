@@ -321,7 +321,16 @@ gp_status gp_ctx_profile_read(gp_ctx *ctx, int which, int64_t *launches, double 
 gp_status gp_probe_mfma_f64(gp_ctx *ctx, double *tflops) {
     if (!ctx || !tflops) return GP_EINVAL;
     GP_HIP(ctx, hipSetDevice(ctx->device));
-    double v = gpk_probe_mfma(ctx->stream, ctx->num_cu);
+    double v = gpk_probe_mfma(ctx->stream, ctx->num_cu, 2, nullptr, nullptr);
+    if (v < 0) { GP_SET_ERR(ctx, "probe allocation failed"); return GP_ENOMEM; }
+    *tflops = v;
+    return GP_OK;
+}
+
+gp_status gp_probe_mfma_f64_ex(gp_ctx *ctx, int waves_per_simd, double *tflops, double *clock_mhz, double *cycles_per_mfma) {
+    if (!ctx || !tflops || waves_per_simd < 1 || waves_per_simd > 2) return GP_EINVAL;
+    GP_HIP(ctx, hipSetDevice(ctx->device));
+    double v = gpk_probe_mfma(ctx->stream, ctx->num_cu, waves_per_simd, clock_mhz, cycles_per_mfma);
     if (v < 0) { GP_SET_ERR(ctx, "probe allocation failed"); return GP_ENOMEM; }
     *tflops = v;
     return GP_OK;

@@ -105,7 +105,7 @@ void gpk_lml(hipStream_t s, const double *L, int n, int ldl, const double *y, co
 // var[i] = kss - sumsq[i]
 void gpk_var_finish(hipStream_t s, double *var, const double *sumsq, int m, double kss);
 void gpk_copy_2d(hipStream_t s, double *dst, int ldd, const double *src, int lds, int rows, int cols);
-double gpk_probe_mfma(hipStream_t s, int num_cu);
+double gpk_probe_mfma(hipStream_t s, int num_cu, int waves_per_simd, double *clock_mhz, double *cycles_per_mfma);
 int gpk_init_kernels();
 int gpk_init_diag_kernels();
 // MFMA-blocked critical-path kernels (kernels_diag.hip).  dinv holds the inverses of the 16x16 diagonal

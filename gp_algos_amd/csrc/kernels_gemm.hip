@@ -153,20 +153,33 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(int M, int N, int K
         }
 }
 
-// register-only MFMA loop: measures the achievable fp64 matrix-core rate (roofline denominator)
-__global__ __launch_bounds__(256) void mfma_probe_kernel(double *out, int iters) {
-    double4_t acc[8];
+// register-only MFMA loop: measures the achievable fp64 matrix-core rate (roofline denominator) with 16
+// independent accumulators per wave, and stamps shader-clock / real-time counters around the loop so the
+// clock the chip holds under fp64 MFMA load and the cycles per v_mfma_f64_16x16x4_f64 can be read off.
+__global__ __launch_bounds__(256) void mfma_probe_kernel(double *out, unsigned long long *stamps, int iters) {
+    double4_t acc[16];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    for (int i = 0; i < 16; ++i) acc[i] = (double4_t){0.0, 0.0, 0.0, 0.0};
     double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int it = 0; it < iters; ++it) {
+        // inline asm with "+v": keeps the accumulators in VGPRs (with the builtin hipcc parks them in AGPRs and
+        // copies all 128 registers back and forth every iteration, which is what a first version of this probe timed)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+        for (int i = 0; i < 16; ++i)
+            asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
     }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     double s = 0.0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if ((threadIdx.x & 63) == 0) {
+        const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+        stamps[2 * w] = c1 - c0;
+        stamps[2 * w + 1] = r1 - r0;
+    }
 }
 
 }  // namespace
@@ -184,24 +197,33 @@ void gpk_gemm_nt(hipStream_t s, int M, int N, int K, double alpha, const double 
     }
 }
 
-double gpk_probe_mfma(hipStream_t s, int num_cu) {
-    const int iters = 20000;
-    const int blocks = num_cu * 2;  // 8 waves per CU = 2 per SIMD
+double gpk_probe_mfma(hipStream_t s, int num_cu, int waves_per_simd, double *clock_mhz, double *cycles_per_mfma) {
+    const int iters = 4000;
+    const int blocks = num_cu * waves_per_simd;   // 4 waves per block = one per SIMD
     double *d = nullptr;
+    unsigned long long *st = nullptr;
     if (hipMalloc(&d, sizeof(double) * blocks * 256) != hipSuccess) return -1.0;
+    if (hipMalloc(&st, sizeof(unsigned long long) * blocks * 8) != hipSuccess) { (void)hipFree(d); return -1.0; }
     hipEvent_t e0, e1;
-    hipEventCreate(&e0);
-    hipEventCreate(&e1);
-    hipLaunchKernelGGL(mfma_probe_kernel, dim3(blocks), dim3(256), 0, s, d, 100);  // warm-up
-    hipEventRecord(e0, s);
-    hipLaunchKernelGGL(mfma_probe_kernel, dim3(blocks), dim3(256), 0, s, d, iters);
-    hipEventRecord(e1, s);
-    hipEventSynchronize(e1);
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    hipLaunchKernelGGL(mfma_probe_kernel, dim3(blocks), dim3(256), 0, s, d, st, 200);  // warm-up
+    (void)hipEventRecord(e0, s);
+    hipLaunchKernelGGL(mfma_probe_kernel, dim3(blocks), dim3(256), 0, s, d, st, iters);
+    (void)hipEventRecord(e1, s);
+    (void)hipEventSynchronize(e1);
     float ms = 0.f;
-    hipEventElapsedTime(&ms, e0, e1);
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
-    hipFree(d);
-    double flops = (double)blocks * 4 /*waves*/ * (double)iters * 8 * (2.0 * 16 * 16 * 4);
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    std::vector<unsigned long long> h(blocks * 8);
+    (void)hipMemcpy(h.data(), st, sizeof(unsigned long long) * blocks * 8, hipMemcpyDeviceToHost);
+    double cyc = 0.0, rt = 0.0;
+    for (int w = 0; w < blocks * 4; ++w) { cyc += (double)h[2 * w]; rt += (double)h[2 * w + 1]; }
+    if (clock_mhz) *clock_mhz = rt > 0 ? cyc / rt * 100.0 : 0.0;               // s_memrealtime ticks at 100 MHz
+    if (cycles_per_mfma) *cycles_per_mfma = cyc / (blocks * 4.0) / ((double)iters * 16.0) / waves_per_simd;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(d);
+    (void)hipFree(st);
+    double flops = (double)blocks * 4 /*waves*/ * (double)iters * 16 * (2.0 * 16 * 16 * 4);
     return flops / (ms * 1e-3) / 1e12;
 }

@@ -60,6 +60,9 @@ gp_status gp_ctx_profile_read(gp_ctx *ctx, int which, int64_t *launches, double 
 /* fp64 MFMA peak probe: runs a register-only v_mfma_f64_16x16x4_f64 loop on every CU and returns
  * the measured TFLOP/s (denominator check for roofline fractions). */
 gp_status gp_probe_mfma_f64(gp_ctx *ctx, double *tflops);
+/* Same with 1 or 2 waves per SIMD; also returns the shader clock held during the loop (s_memtime / s_memrealtime)
+ * and the SIMD cycles per MFMA instruction, so a roofline fraction can be quoted against the ACHIEVABLE rate. */
+gp_status gp_probe_mfma_f64_ex(gp_ctx *ctx, int waves_per_simd, double *tflops, double *clock_mhz, double *cycles_per_mfma);
 /* device memory helpers for callers without their own allocator (the JNI shim) */
 gp_status gp_dev_alloc(gp_ctx *ctx, size_t bytes, void **dptr);
 gp_status gp_dev_free(gp_ctx *ctx, void *dptr);
