@@ -149,9 +149,13 @@ void back_solve_vec(gp_ctx *ctx, const double *L, int np, int ldl, const double 
 void solve_rows_lower(gp_ctx *ctx, double *Vt, int mp, const double *L, int np, int ldl, const double *dinv, double *sumsq) {
     hipStream_t s = ctx->stream;
     const int nblk = np / GP_NB;
+    // Few rows (mp/128 tiles per step would leave most of the 256 CUs idle): right-looking -- after block column i is
+    // solved, ALL later block columns are updated by one wide GEMM (K = 128).  Many rows (the posterior batches):
+    // left-looking -- each block column is hit once by a long-K GEMM, the most efficient shape for the MFMA kernel.
+    const bool right_looking = (mp / GP_NB) < 192;
     for (int i = 0; i < nblk; ++i) {
         double *Vi = Vt + (size_t)i * GP_NB * mp;
-        if (i > 0) {
+        if (!right_looking && i > 0) {
             gp_prof_begin(ctx, GP_PROF_GEMM);
             gpk_gemm_nt(s, mp, GP_NB, i * GP_NB, -1.0, Vt, mp, L + (size_t)i * GP_NB, ldl, 1.0, Vi, mp, 0);
             gp_prof_end(ctx, GP_PROF_GEMM, 2.0 * mp * GP_NB * (double)i * GP_NB);
@@ -159,6 +163,38 @@ void solve_rows_lower(gp_ctx *ctx, double *Vt, int mp, const double *L, int np, 
         gp_prof_begin(ctx, GP_PROF_TRSM);
         gpk_trsm_panel128(s, Vi, mp, mp, L + (size_t)i * GP_NB + (size_t)i * GP_NB * ldl, ldl, dinv + (size_t)i * GP_NB * 16, sumsq);
         gp_prof_end(ctx, GP_PROF_TRSM, (double)mp * GP_NB * GP_NB);
+        const int rest = np - (i + 1) * GP_NB;
+        if (right_looking && rest > 0) {
+            gp_prof_begin(ctx, GP_PROF_GEMM);
+            gpk_gemm_nt(s, mp, rest, GP_NB, -1.0, Vi, mp, L + (size_t)(i + 1) * GP_NB + (size_t)i * GP_NB * ldl, ldl, 1.0,
+                        Vt + (size_t)(i + 1) * GP_NB * mp, mp, 0);
+            gp_prof_end(ctx, GP_PROF_GEMM, 2.0 * mp * (double)rest * GP_NB);
+        }
+    }
+}
+
+// T (np x np) <- L^-T, i.e. the identity solved against L in row form, RIGHT-looking: after block column i of T is
+// final (rows 0 .. (i+1)*128 only -- T is upper triangular), every later block column is updated at once:
+//   T[0:(i+1)*128, j] -= T_i * L[j-block, i-block]^T   for all j > i    (M = (i+1)*128, N = np-(i+1)*128, K = 128).
+// Same n^3/3 flops as a structure-exploiting left-looking solve, but each step is one wide GEMM (up to n^2/4/128^2
+// tiles) instead of an (np/128)-tile one -- at n = 4096 the left-looking form keeps 32 of 256 CUs busy.
+void inverse_transpose_lower(gp_ctx *ctx, double *T, const double *L, int np, int ldl, const double *dinv) {
+    hipStream_t s = ctx->stream;
+    const int nblk = np / GP_NB;
+    gpk_set_identity(s, T, np, np);
+    for (int i = 0; i < nblk; ++i) {
+        const int rows = (i + 1) * GP_NB;   // non-zero rows of block column i
+        double *Ti = T + (size_t)i * GP_NB * np;
+        gp_prof_begin(ctx, GP_PROF_TRSM);
+        gpk_trsm_panel128(s, Ti, rows, np, L + (size_t)i * GP_NB + (size_t)i * GP_NB * ldl, ldl, dinv + (size_t)i * GP_NB * 16, nullptr);
+        gp_prof_end(ctx, GP_PROF_TRSM, (double)rows * GP_NB * GP_NB);
+        const int rest = np - rows;
+        if (rest > 0) {
+            gp_prof_begin(ctx, GP_PROF_GEMM);
+            gpk_gemm_nt(s, rows, rest, GP_NB, -1.0, Ti, np, L + (size_t)rows + (size_t)i * GP_NB * ldl, ldl, 1.0,
+                        T + (size_t)rows * np, np, 0);
+            gp_prof_end(ctx, GP_PROF_GEMM, 2.0 * rows * (double)rest * GP_NB);
+        }
     }
 }
 
@@ -257,7 +293,23 @@ gp_status gp_ctx_create(int device, void *stream, gp_ctx **out) {
         if (stream) { ctx->stream = static_cast<hipStream_t>(stream); ctx->own_stream = false; }
         else { e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking); ctx->own_stream = true; }
     }
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking);
+    if (e == hipSuccess) {
+        // Side stream for the far trailing update of the Cholesky.  It is CU-masked to leave a few CUs free of its
+        // long-running GEMM workgroups: the single-workgroup diagonal-block kernel on the main stream needs ~150 KB
+        // of LDS, i.e. a whole CU, and otherwise waits hundreds of microseconds for two GEMM workgroups on one CU
+        // to retire together.  GPCORE_RESERVED_CUS (default 8, 0 = no mask) sets how many CUs stay reserved.
+        int reserved = 8;
+        if (const char *rc = getenv("GPCORE_RESERVED_CUS")) reserved = atoi(rc);
+        hipError_t em = hipErrorInvalidValue;
+        if (reserved > 0 && ctx->num_cu >= 64) {
+            const int words = (ctx->num_cu + 31) / 32;
+            std::vector<uint32_t> mask(words, 0xFFFFFFFFu);
+            if (ctx->num_cu % 32) mask[words - 1] = (1u << (ctx->num_cu % 32)) - 1u;
+            for (int i = 0; i < reserved; ++i) mask[i % words] &= ~(1u << (i / words));   // spread over the mask words
+            em = hipExtStreamCreateWithCUMask(&ctx->side, (uint32_t)words, mask.data());
+        }
+        if (em != hipSuccess) { (void)hipGetLastError(); e = hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking); }
+    }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_a, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_b, hipEventDisableTiming);
     if (const char *la = getenv("GPCORE_LOOKAHEAD")) ctx->lookahead = atoi(la) != 0;
@@ -702,8 +754,7 @@ extern "C" gp_status gp_lml_grad_rbf_batched(gp_ctx *ctx, const double *X, int n
         st = gp_model_refit_dev(m, theta, sigma_noise);
         if (st != GP_OK) break;
         if (nparams > 0) {
-            gpk_set_identity(s, T, np, np);
-            solve_rows_lower(ctx, T, np, m->dL, np, m->ldl, m->ddinv, nullptr);   // T = L^-T (upper triangular)
+            inverse_transpose_lower(ctx, T, m->dL, np, m->ldl, m->ddinv);     // T = L^-T (upper triangular)
             gp_prof_begin(ctx, GP_PROF_SYRK);
             gpk_gemm_nt(s, np, np, np, 1.0, T, np, T, np, 0.0, Kinv, np, 1, 1);  // Kinv = T T^T, lower
             gp_prof_end(ctx, GP_PROF_SYRK, (double)np * np * np / 3.0);

@@ -26,19 +26,38 @@ namespace {
 constexpr int TM = 128, TN = 128, TK = GP_BK;
 constexpr int LDS_STRIDE = TM + 16;  // doubles
 
-__device__ __forceinline__ void tile_coords_lower(int t, int nbm, int &bi, int &bj) {
-    // lower trapezoid of an (nbm x nbn) tile grid, nbm >= nbn, enumerated column by column:
-    // column bj holds tiles bi = bj .. nbm-1 and starts at S(bj) = bj*nbm - bj*(bj-1)/2.
-    const double c = 2.0 * nbm + 1.0;
-    int b = (int)((c - sqrt(c * c - 8.0 * (double)t)) * 0.5);
-    if (b < 0) b = 0;
-    while (b > 0 && b * nbm - b * (b - 1) / 2 > t) --b;
-    while ((b + 1) * nbm - (b + 1) * b / 2 <= t) ++b;
-    bj = b;
-    bi = b + (t - (b * nbm - b * (b - 1) / 2));
+__device__ __forceinline__ void tile_coords_lower(int t, int nbm, int nbn, int &bi, int &bj) {
+    // Lower trapezoid of an (nbm x nbn) tile grid, nbm >= nbn, enumerated in SUPER-COLUMNS of G = 4 tile columns:
+    // inside a super-column tiles run row by row (bi ascending, its <= 4 columns innermost).  Tiles that are
+    // consecutive in this order share their A row panel and cycle through the same 4 B panels, so the working set
+    // of one XCD (4 B panels + a streaming A panel, ~2.6 MB at K = 512) stays in its 4 MB L2 instead of
+    // re-fetching 2 x 0.5 MB of panels per tile.
+    constexpr int G = 4;
+    for (int c0 = 0; c0 < nbn; c0 += G) {
+        const int w = (nbn - c0 < G) ? nbn - c0 : G;
+        const int head = w * (w + 1) / 2;                  // rows c0 .. c0+w-1 hold 1 .. w tiles
+        const int total = head + (nbm - c0 - w) * w;       // then full rows of w tiles
+        if (t < total) {
+            int r, c;
+            if (t < head) {
+                r = 0;
+                while ((r + 1) * (r + 2) / 2 <= t) ++r;
+                c = t - r * (r + 1) / 2;
+            } else {
+                const int u = t - head;
+                r = w + u / w;
+                c = u % w;
+            }
+            bi = c0 + r;
+            bj = c0 + c;
+            return;
+        }
+        t -= total;
+    }
+    bi = bj = 0;   // not reached for a valid launch
 }
 
-template <int LOWER>
+template <int LOWER, int HAS_BETA>
 __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(int M, int N, int K, double alpha, const double *__restrict__ A, int lda,
                                                            const double *__restrict__ B, int ldb, double beta,
                                                            double *__restrict__ C, int ldc, int ktri) {
@@ -48,7 +67,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(int M, int N, int K
 
     int bi, bj;
     if (LOWER) {
-        tile_coords_lower(blockIdx.x, M / TM, bi, bj);
+        // XCD-aware: block ids are dealt round-robin over the 8 XCDs; hand each XCD a contiguous run of the order above
+        const int nwg = gridDim.x, id = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = id & 7;
+        const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+        tile_coords_lower(swz, M / TM, N / TN, bi, bj);
     } else {
         // XCD-aware: consecutive block ids round-robin over the 8 XCDs; give each XCD a contiguous
         // run of tiles that share the same B panel (bj) so the panel stays in that XCD's L2.
@@ -134,23 +157,36 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(int M, int N, int K
         __syncthreads();
     }
 
-    // epilogue: acc[nt][mt][r] = D[n = wn + nt*16 + fk + 4r][m = wm + mt*16 + fr]
+    // epilogue: acc[nt][mt][r] = D[n = wn + nt*16 + fk + 4r][m = wm + mt*16 + fr].
+    // C is read in batches of 16 independent loads per 16-column group, then written: a load/wait/store chain per
+    // element (what a naive `v += beta * *cp` compiles to) serialises 64 memory round trips per tile.
     const bool diag_tile = LOWER && (bi == bj);
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
+    for (int nt = 0; nt < 4; ++nt) {
+        double cv[4][4];
+        if (HAS_BETA) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = col0 + wn + nt * 16 + fk + 4 * r;
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    const int m = row0 + wm + mt * 16 + fr;
+                    cv[r][mt] = (diag_tile && m < n) ? 0.0 : C[m + (size_t)n * ldc];
+                }
+            }
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int n = col0 + wn + nt * 16 + fk + 4 * r;
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
                 const int m = row0 + wm + mt * 16 + fr;
-                if (diag_tile && m < n) continue;
-                double *cp = C + m + (size_t)n * ldc;
                 double v = alpha * acc[nt][mt][r];
-                if (beta != 0.0) v += beta * (*cp);
-                *cp = v;
+                if (HAS_BETA) v = fma(beta, cv[r][mt], v);
+                if (!(diag_tile && m < n)) C[m + (size_t)n * ldc] = v;
             }
         }
+    }
 }
 
 // register-only MFMA loop: measures the achievable fp64 matrix-core rate (roofline denominator) with 16
@@ -187,13 +223,16 @@ __global__ __launch_bounds__(256) void mfma_probe_kernel(double *out, unsigned l
 void gpk_gemm_nt(hipStream_t s, int M, int N, int K, double alpha, const double *A, int lda, const double *B, int ldb,
                  double beta, double *C, int ldc, int lower, int ktri) {
     if (M <= 0 || N <= 0) return;
+    const bool hb = beta != 0.0;
     if (lower) {
         int nbm = M / TM, nbn = N / TN;   // trapezoid: M >= N
         int ntiles = nbn * nbm - nbn * (nbn - 1) / 2;
-        hipLaunchKernelGGL(gemm_nt_f64_kernel<1>, dim3(ntiles), dim3(256), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, ktri);
+        if (hb) hipLaunchKernelGGL((gemm_nt_f64_kernel<1, 1>), dim3(ntiles), dim3(256), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, ktri);
+        else hipLaunchKernelGGL((gemm_nt_f64_kernel<1, 0>), dim3(ntiles), dim3(256), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, ktri);
     } else {
         int ntiles = (M / TM) * (N / TN);
-        hipLaunchKernelGGL(gemm_nt_f64_kernel<0>, dim3(ntiles), dim3(256), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, ktri);
+        if (hb) hipLaunchKernelGGL((gemm_nt_f64_kernel<0, 1>), dim3(ntiles), dim3(256), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, ktri);
+        else hipLaunchKernelGGL((gemm_nt_f64_kernel<0, 0>), dim3(ntiles), dim3(256), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, ktri);
     }
 }
 
