@@ -25,8 +25,9 @@ struct gp_ep {
     double *dinv = nullptr;   // np x 16
     double *S = nullptr;      // np x 128 panel of delayed columns
     double *Sc = nullptr;     // np x 128 panel scaled by c
+    double *blk = nullptr;    // 128 x 128 unit-lower block factor + its 8 tile inverses
     double *vec = nullptr;    // 10 x np: tau, nu, tau_old, nu_old, mu, cav_tau, cav_nu, st, tmp1, tmp2
-    double *cvec = nullptr;   // 128 + 2 (mu slots)
+    double *cvec = nullptr;   // 128 c + 128 (-coef)
     int *y = nullptr;
     int sweeps = 0;
     double *tau() { return vec; }
@@ -46,64 +47,77 @@ namespace {
 __device__ __forceinline__ double dnorm_d(double x) { return exp(-(x * x) / 2.0 - log(sqrt(2.0 * M_PI))); }   // StatsUtils.scala:15
 __device__ __forceinline__ double pnorm_d(double x) { return 0.5 * (1.0 + erf(x / sqrt(2.0))); }              // StatsUtils.scala:17
 
-// One site update (EpParameterEstimator.scala:45-54) against the delayed-update state.
-__global__ __launch_bounds__(256) void ep_site_kernel(int n, int np, int i, int t, const double *__restrict__ Sig0,
-                                                      double *__restrict__ S, double *__restrict__ cvec, const int *__restrict__ y,
-                                                      const double *__restrict__ tau_old, const double *__restrict__ nu_old,
-                                                      double *__restrict__ tau, double *__restrict__ nu,
-                                                      double *__restrict__ cav_tau, double *__restrict__ cav_nu,
-                                                      double *__restrict__ mu, double *__restrict__ mu_slot) {
-    __shared__ double w[GP_NB];
-    __shared__ double red[256];
-    __shared__ double sc[2];
-    const int tid = threadIdx.x;
-    double part = 0.0;
-    if (tid < t) {
-        const double sq = S[i + (size_t)tid * np], cq = cvec[tid];
-        w[tid] = cq * sq;
-        part = (cq * sq) * sq;
+// All site updates of one block of <= 128 consecutive sites (EpParameterEstimator.scala:44-55), on chip, by ONE
+// workgroup.  Inside a block the recurrence only ever touches the block's own rows:
+//   s_t[r] = Sigma0[r, i_t] - sum_{q<t} c_q S[r,q] S[i_t,q]      (r in the block)
+//   mu[r] += s_t[r] (dnu - c_t (mu_i + dnu s_ii))                 (O(n) form of mu = Sigma nu, Appendix A.3)
+// so the 128 x 128 diagonal block of Sigma0, the block of S and mu live in LDS for the whole block.  Outputs: the new
+// site/cavity parameters, c, -coef, and Lmat = I + strict_lower(S_blk diag(c)) -- the unit-lower factor with which the
+// full-height columns follow afterwards from ONE row-panel solve,  S = Sigma0[:, blk] Lmat^-T  (trsm_panel128).
+__global__ __launch_bounds__(128) void ep_block_kernel(int n, int np, int i0, int bsz, const double *__restrict__ Sig0,
+                                                       const double *__restrict__ mu, const int *__restrict__ y,
+                                                       double *__restrict__ tau, double *__restrict__ nu,
+                                                       double *__restrict__ cav_tau, double *__restrict__ cav_nu,
+                                                       double *__restrict__ cvec, double *__restrict__ ncoef,
+                                                       double *__restrict__ Lmat) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    constexpr int LS = GP_NB + 1;
+    double *A = sm;                  // column c: Sigma0[blk, i0+c] until site c is processed, afterwards s_c[blk]
+    double *Sb = sm;                 //   (the delayed column replaces the Sigma0 column it was built from)
+    double *w = sm + GP_NB * LS;     // c_q * S[i_t, q]
+    double *cs = w + GP_NB;          // c
+    double *mb = cs + GP_NB;         // mu restricted to the block
+    double *sc = mb + GP_NB;         // scalars: [0] coef
+    const int r = threadIdx.x;
+#pragma unroll
+    for (int c0 = 0; c0 < GP_NB; c0 += 16) {   // 16 loads in flight per thread (a load/wait/store loop would cost ~100 us)
+        double v[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) v[c] = Sig0[(i0 + r) + (size_t)(i0 + c0 + c) * np];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) A[r + (c0 + c) * LS] = v[c];
     }
-    red[tid] = part;
+    mb[r] = (i0 + r < n) ? mu[i0 + r] : 0.0;
+    cs[r] = 0.0;
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (tid < s) red[tid] += red[tid + s];
+    for (int t = 0; t < bsz; ++t) {
+        if (r < t) w[r] = cs[r] * Sb[t + r * LS];
         __syncthreads();
-    }
-    if (tid == 0) {
-        const double sii = Sig0[i + (size_t)i * np] - red[0];
-        const double mui = mu_slot[i & 1];
-        const double to = tau_old[i], no = nu_old[i];
-        const double tc = 1.0 / sii - to;                      // :45
-        const double nc = mui / sii - no;                      // :46
-        const double cm = nc / tc, cs = 1.0 / tc;              // marginalMoments(ni/tau, 1/tau, y) :47-48
-        const int yi = y[i];
-        const double temp = sqrt(1.0 + cs);
-        const double z = (yi * cm) / temp;
-        const double dz = dnorm_d(z), pz = pnorm_d(z);
-        const double mi_hat = cm + (yi * cs * dz) / (pz * temp);
-        const double sg_hat = cs - ((cs * cs * dz) * (z + dz / pz)) / ((1.0 + cs) * pz);
-        const double dtau = 1.0 / sg_hat - tc - to;            // :49
-        const double tn = to + dtau;                           // :50
-        const double nn = mi_hat / sg_hat - nc;                // :51
-        const double c = 1.0 / (1.0 / dtau + sii);             // :53
-        const double dnu = nn - no;
-        sc[0] = dnu - c * (mui + dnu * sii);
-        sc[1] = c;
-        if (blockIdx.x == 0) { tau[i] = tn; nu[i] = nn; cav_tau[i] = tc; cav_nu[i] = nc; cvec[t] = c; }
-    }
-    __syncthreads();
-    const double coef = sc[0];
-    const int p = blockIdx.x * 256 + tid;
-    if (p < np) {
-        double sp = Sig0[p + (size_t)i * np];
-        for (int q = 0; q < t; ++q) sp = fma(-w[q], S[p + (size_t)q * np], sp);
-        S[p + (size_t)t * np] = sp;
-        if (p < n) {
-            const double m = fma(sp, coef, mu[p]);
-            mu[p] = m;
-            if (p == i + 1) mu_slot[(i + 1) & 1] = m;
+        double sp = A[r + t * LS];
+        for (int q = 0; q < t; ++q) sp = fma(-w[q], Sb[r + q * LS], sp);
+        Sb[r + t * LS] = sp;
+        if (r == t) {
+            const int i = i0 + t;
+            const double sii = sp, mui = mb[t];
+            const double to = tau[i], no = nu[i];
+            const double tc = 1.0 / sii - to;                      // :45
+            const double nc = mui / sii - no;                      // :46
+            const double cm = nc / tc, cvr = 1.0 / tc;             // marginalMoments(ni/tau, 1/tau, y) :47-48
+            const int yi = y[i];
+            const double temp = sqrt(1.0 + cvr);
+            const double z = (yi * cm) / temp;
+            const double dz = dnorm_d(z), pz = pnorm_d(z);
+            const double mi_hat = cm + (yi * cvr * dz) / (pz * temp);
+            const double sg_hat = cvr - ((cvr * cvr * dz) * (z + dz / pz)) / ((1.0 + cvr) * pz);
+            const double dtau = 1.0 / sg_hat - tc - to;            // :49
+            const double tn = to + dtau;                           // :50
+            const double nn = mi_hat / sg_hat - nc;                // :51
+            const double c = 1.0 / (1.0 / dtau + sii);             // :53
+            const double dnu = nn - no;
+            const double coef = dnu - c * (mui + dnu * sii);
+            sc[0] = coef;
+            cs[t] = c;
+            tau[i] = tn; nu[i] = nn; cav_tau[i] = tc; cav_nu[i] = nc;
+            cvec[t] = c;
+            ncoef[t] = -coef;
         }
+        __syncthreads();
+        mb[r] = fma(sp, sc[0], mb[r]);
     }
+    if (r >= bsz) { cvec[r] = 0.0; ncoef[r] = 0.0; }
+    __syncthreads();
+    for (int c = 0; c < GP_NB; ++c)
+        Lmat[r + (size_t)c * GP_NB] = (r == c) ? 1.0 : ((r > c && c < bsz) ? Sb[r + c * LS] * cs[c] : 0.0);
 }
 
 __global__ void scale_cols_kernel(double *__restrict__ dst, const double *__restrict__ src, const double *__restrict__ c, int rows, int cols, int ld) {
@@ -182,8 +196,7 @@ __global__ __launch_bounds__(1024) void ep_lml_kernel(int n, int np, const doubl
     if (threadIdx.x == 0) out[0] = red[0];
 }
 
-__global__ void set_slot_kernel(double *slot, const double *mu) { slot[0] = mu[0]; slot[1] = 0.0; }
-
+constexpr int EP_BLOCK_LDS = (GP_NB * (GP_NB + 1) + 3 * GP_NB + 8) * (int)sizeof(double);
 inline dim3 g1(int n) { return dim3((n + 255) / 256); }
 
 // end of sweep: L, Sigma, mu from the current site parameters (EpParameterEstimator.scala:56-61)
@@ -210,7 +223,6 @@ gp_status ep_refactor(gp_ep *ep) {
     double *partial;
     GP_TRY(gpi_ws_get(ctx, WS_PARTIAL, sizeof(double) * (size_t)16 * np, &partial));
     gpk_gemv_rows(s, ep->Sig, n, n, np, ep->nu(), ep->mu(), partial, 16);
-    hipLaunchKernelGGL(set_slot_kernel, dim3(1), dim3(1), 0, s, ep->cvec + GP_NB, ep->mu());
     return GP_OK;
 }
 
@@ -224,6 +236,7 @@ gp_status gp_ep_create(gp_ctx *ctx, const double *K, int n, int ldk, const int32
     GP_REQUIRE(ctx, K && y && n >= 1 && ldk >= n, "bad arguments");   // require(kernelMatrix.rows == targets.length)
     for (int i = 0; i < n; ++i) GP_REQUIRE(ctx, y[i] == 1 || y[i] == -1, "targets must contain values from set {-1,1}");
     GP_HIP(ctx, hipSetDevice(ctx->device));
+    GP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(ep_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, EP_BLOCK_LDS));
     gp_ep *ep = new (std::nothrow) gp_ep();
     if (!ep) return GP_ENOMEM;
     ep->ctx = ctx; ep->n = n; ep->np = gp_pad(n);
@@ -234,14 +247,15 @@ gp_status gp_ep_create(gp_ctx *ctx, const double *K, int n, int ldk, const int32
     if (e == hipSuccess) e = hipMalloc(&ep->dinv, np * 16 * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&ep->S, np * GP_NB * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&ep->Sc, np * GP_NB * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&ep->blk, (GP_NB * GP_NB + 8 * 256) * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&ep->vec, 10 * np * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc(&ep->cvec, (GP_NB + 2) * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&ep->cvec, 2 * GP_NB * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&ep->y, np * sizeof(int));
     hipStream_t s = ctx->stream;
     if (e == hipSuccess) e = hipMemsetAsync(ep->K, 0, nn, s);
     if (e == hipSuccess) e = hipMemsetAsync(ep->L, 0, nn, s);
     if (e == hipSuccess) e = hipMemsetAsync(ep->vec, 0, 10 * np * sizeof(double), s);
-    if (e == hipSuccess) e = hipMemsetAsync(ep->cvec, 0, (GP_NB + 2) * sizeof(double), s);
+    if (e == hipSuccess) e = hipMemsetAsync(ep->cvec, 0, 2 * GP_NB * sizeof(double), s);
     if (e == hipSuccess) e = hipMemsetAsync(ep->y, 0, np * sizeof(int), s);
     if (e == hipSuccess) e = hipMemcpyAsync(ep->y, y, n * sizeof(int), hipMemcpyHostToDevice, s);
     if (e != hipSuccess) { GP_SET_ERR(ctx, "EP allocation (n=%d) failed: %s", n, hipGetErrorString(e)); gp_ep_destroy(ep); return GP_ENOMEM; }
@@ -264,15 +278,18 @@ gp_status gp_ep_sweep(gp_ep *ep, int nsweeps, double *tau, double *nu, int *info
     if (info) *info = 0;
     GP_HIP(ctx, hipMemsetAsync(ctx->d_info, 0, sizeof(int), s));
     for (int sw = 0; sw < nsweeps; ++sw) {
-        GP_HIP(ctx, hipMemcpyAsync(ep->tau_old(), ep->tau(), sizeof(double) * 2 * (size_t)np, hipMemcpyDeviceToDevice, s));  // tau,nu -> old
         for (int i0 = 0; i0 < n; i0 += GP_NB) {
             const int bsz = (n - i0 < GP_NB) ? n - i0 : GP_NB;
-            for (int t = 0; t < bsz; ++t)
-                hipLaunchKernelGGL(ep_site_kernel, g1(np), dim3(256), 0, s, n, np, i0 + t, t, ep->Sig, ep->S, ep->cvec, ep->y,
-                                   ep->tau_old(), ep->nu_old(), ep->tau(), ep->nu(), ep->cav_tau(), ep->cav_nu(), ep->mu(),
-                                   ep->cvec + GP_NB);
+            double *Lmat = ep->blk, *bdinv = ep->blk + GP_NB * GP_NB;
+            double *ncoef = ep->cvec + GP_NB;
+            hipLaunchKernelGGL(ep_block_kernel, dim3(1), dim3(GP_NB), EP_BLOCK_LDS, s, n, np, i0, bsz, ep->Sig, ep->mu(), ep->y,
+                               ep->tau(), ep->nu(), ep->cav_tau(), ep->cav_nu(), ep->cvec, ncoef, Lmat);
+            // full-height delayed columns S = Sigma0[:, blk] Lmat^-T, then mu += S coef for every row
+            gpk_copy_2d(s, ep->S, np, ep->Sig + (size_t)i0 * np, np, np, GP_NB);
+            gpk_tile_inverses(s, Lmat, GP_NB, GP_NB, bdinv);
+            gpk_trsm_panel128(s, ep->S, np, np, Lmat, GP_NB, bdinv, nullptr);
+            gpk_gemv_panel_sub(s, ep->S, n, np, ncoef, ep->mu());
             if (i0 + bsz < n) {   // the last block's update would only feed a Sigma that the refactorisation discards (:60)
-                if (bsz < GP_NB) gpk_fill(s, ep->S + (size_t)bsz * np, (size_t)(GP_NB - bsz) * np, 0.0);
                 hipLaunchKernelGGL(scale_cols_kernel, dim3(512), dim3(256), 0, s, ep->Sc, ep->S, ep->cvec, np, GP_NB, np);
                 gp_prof_begin(ctx, GP_PROF_GEMM);
                 gpk_gemm_nt(s, np, np, GP_NB, -1.0, ep->Sc, np, ep->S, np, 1.0, ep->Sig, np, 0);
@@ -368,7 +385,7 @@ gp_status gp_ep_predict(gp_ep *ep, const double *Ks, int m, int ldks, const doub
 void gp_ep_destroy(gp_ep *ep) {
     if (!ep) return;
     if (ep->ctx) { (void)hipSetDevice(ep->ctx->device); (void)hipStreamSynchronize(ep->ctx->stream); }
-    void *ptrs[] = {ep->K, ep->Sig, ep->L, ep->dinv, ep->S, ep->Sc, ep->vec, ep->cvec, ep->y};
+    void *ptrs[] = {ep->K, ep->Sig, ep->L, ep->dinv, ep->S, ep->Sc, ep->blk, ep->vec, ep->cvec, ep->y};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete ep;
 }
