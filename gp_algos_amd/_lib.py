@@ -55,6 +55,7 @@ SIGNATURES = {
     "gp_ep_sweep": (_i, [_vp, _i, _dp, _dp, _ip]),
     "gp_ep_set_site_params": (_i, [_vp, _dp, _dp, _ip]),
     "gp_ep_lml": (_i, [_vp, _i, _dp]),
+    "gp_ep_lml_grad_rbf": (_i, [_vp, _dp, _i, _i, _dp, _i, _dp]),
     "gp_ep_get": (_i, [_vp, _i, _dp, _i]),
     "gp_ep_predict": (_i, [_vp, _dp, _i, _i, _dp, _dp]),
     "gp_ep_destroy": (None, [_vp]),

@@ -250,6 +250,14 @@ class EpClassifierState:
         self.ctx.check(self.ctx._lib.gp_ep_lml(self.h, int(bool(strict)), C.byref(v)))
         return v.value
 
+    def lml_grad_rbf(self, X, theta, strict=True):
+        X, theta = L.f64(X), L.f64(theta)
+        if X.shape[0] != self.n or theta.size != X.shape[1] + 2:
+            raise ValueError("dimension mismatch")
+        g = np.zeros(theta.size)
+        self.ctx.check(self.ctx._lib.gp_ep_lml_grad_rbf(self.h, L.dptr(X), X.shape[1], self.n, L.dptr(theta), int(bool(strict)), L.dptr(g)))
+        return g
+
     def get(self, what):
         mat = what in (L.GP_EP_GET_L, L.GP_EP_GET_SIGMA)
         out = np.zeros((self.n, self.n), order="F") if mat else np.zeros(self.n)

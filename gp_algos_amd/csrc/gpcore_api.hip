@@ -263,6 +263,7 @@ gp_status gpi_download_2d(gp_ctx *ctx, double *dst, int ldd, const double *src, 
 gp_status gpi_read_info(gp_ctx *ctx, int *info) { return read_info(ctx, info); }
 void gpi_chol_blocked(gp_ctx *ctx, double *A, int np, int lda, double *dinv, int extra) { chol_blocked(ctx, A, np, lda, dinv, extra); }
 void gpi_solve_rows_lower(gp_ctx *ctx, double *Vt, int mp, const double *L, int np, int ldl, const double *dinv, double *sumsq) { solve_rows_lower(ctx, Vt, mp, L, np, ldl, dinv, sumsq); }
+void gpi_inverse_transpose_lower(gp_ctx *ctx, double *T, const double *L, int np, int ldl, const double *dinv) { inverse_transpose_lower(ctx, T, L, np, ldl, dinv); }
 void gpi_back_solve_vec(gp_ctx *ctx, const double *L, int np, int ldl, const double *dinv, double *z, double *alpha) { back_solve_vec(ctx, L, np, ldl, dinv, z, alpha); }
 // z <- L^-1 t (t is consumed): one fused launch per block step
 void gpi_forward_solve_vec(gp_ctx *ctx, const double *L, int np, int ldl, const double *dinv, double *t, double *z) {
@@ -649,7 +650,16 @@ gp_status gp_predict_dev(gp_model *mdl, const double *dXs, int m, int ldxs, doub
     gp_ctx *ctx = mdl->ctx;
     GP_REQUIRE(ctx, mdl->has_x, "model was built from a Gram matrix");
     GP_REQUIRE(ctx, dXs && dmean && m >= 1 && ldxs >= m, "bad arguments");
-    return predict_core(mdl, dXs, m, ldxs, dmean, dvar, nullptr, nullptr);
+    // The (batch x n) workspace Vt is never materialised for all m at once (config C5: 10^6 x 32768 doubles = 262 GB):
+    // test points go through in batches whose Vt stays under ~32 GiB; 65 536 rows per batch already fill the chip.
+    const size_t budget = (size_t)32 << 30;
+    int batch = (int)std::min<size_t>((size_t)m, std::max<size_t>(GP_NB, (budget / ((size_t)mdl->np * 8)) / GP_NB * GP_NB));
+    batch = std::min(batch, 65536);
+    for (int lo = 0; lo < m; lo += batch) {
+        const int mb = std::min(batch, m - lo);
+        GP_TRY(predict_core(mdl, dXs + lo, mb, ldxs, dmean + lo, dvar ? dvar + lo : nullptr, nullptr, nullptr));
+    }
+    return GP_OK;
 }
 
 gp_status gp_predict(gp_model *mdl, const double *Xs, int m, int ldxs, double *mean, double *var_diag, double *cov, int ldc) {

@@ -156,6 +156,19 @@ __global__ void vec_sqrt_kernel(double *__restrict__ out, const double *__restri
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < np) out[i] = (i < n) ? sqrt(in[i]) : 0.0;
 }
+__global__ void vec_div_kernel(double *__restrict__ out, const double *__restrict__ a, const double *__restrict__ b, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = a[i] / b[i];
+}
+__global__ void vec_sub_kernel(double *__restrict__ out, const double *__restrict__ a, const double *__restrict__ b, int n, int np) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < np) out[i] = (i < n) ? a[i] - b[i] : 0.0;
+}
+// M(i,j) = st_i * M(i,j) * st_j on the lower triangle
+__global__ void scale_sym_lower_kernel(double *__restrict__ M, const double *__restrict__ st, int n, int ld) {
+    const int j = blockIdx.y;
+    for (int i = j + blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) M[i + (size_t)j * ld] *= st[i] * st[j];
+}
 __global__ void vec_mul_kernel(double *__restrict__ out, const double *__restrict__ a, const double *__restrict__ b, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = a[i] * b[i];
@@ -333,6 +346,48 @@ gp_status gp_ep_lml(gp_ep *ep, int strict, double *lml) {
     hipLaunchKernelGGL(ep_lml_kernel, dim3(1), dim3(1024), 0, ctx->stream, ep->n, ep->np, ep->L, ep->tau(), ep->nu(), ep->mu(),
                        ep->cav_tau(), ep->cav_nu(), ep->y, strict, ctx->d_scalars);
     return gpi_download_2d(ctx, lml, 1, ctx->d_scalars, 1, 1, 1);
+}
+
+gp_status gp_ep_lml_grad_rbf(gp_ep *ep, const double *X, int d, int ldx, const double *theta, int strict, double *grad) {
+    if (!ep) return GP_EINVAL;
+    gp_ctx *ctx = ep->ctx;
+    const int n = ep->n, np = ep->np;
+    GP_REQUIRE(ctx, X && theta && grad && d >= 1 && d <= 64 && ldx >= n, "bad arguments (1 <= d <= 64)");
+    GP_REQUIRE(ctx, ep->sweeps > 0, "no sweep has run yet");
+    GP_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const int P = d + 2;
+    double *dX, *partial, *parts, *dres;
+    GP_TRY(gpi_ws_get(ctx, WS_A, sizeof(double) * (size_t)n * d, &dX));
+    GP_TRY(gpi_ws_get(ctx, WS_PARTIAL, sizeof(double) * (size_t)16 * np, &partial));
+    GP_TRY(gpi_ws_get(ctx, WS_SUMSQ, sizeof(double) * (size_t)gpk_lml_grad_partials_size(n, d), &parts));
+    GP_TRY(gpi_ws_get(ctx, WS_C, sizeof(double) * (size_t)(P + 1), &dres));
+    GP_TRY(gpi_upload_2d(ctx, dX, n, X, ldx, n, d));
+    double *t1 = ep->tmp1(), *t2 = ep->tmp2();
+    // rhs = S^1/2 K nu                                                    MarginalLikelihoodEvaluator.scala:53-54
+    gpk_gemv_rows(s, ep->K, n, n, np, ep->nu(), t1, partial, 16);
+    hipLaunchKernelGGL(vec_mul_kernel, g1(n), dim3(256), 0, s, t1, t1, ep->st(), n);
+    const double *Kinv = nullptr;
+    if (strict) {
+        gpi_back_solve_vec(ctx, ep->L, np, np, ep->dinv, t1, t2);                       // temp = L^T \ rhs           :53
+        hipLaunchKernelGGL(vec_div_kernel, g1(n), dim3(256), 0, s, t2, t2, ep->st(), n);   // (S^1/2 L) x = temp  <=>  L x = temp / st
+        gpi_forward_solve_vec(ctx, ep->L, np, np, ep->dinv, t2, t1);                    //                              :55-56
+        hipLaunchKernelGGL(vec_sub_kernel, g1(np), dim3(256), 0, s, t2, ep->nu(), t1, n, np);   // b = nu - x
+    } else {
+        gpi_forward_solve_vec(ctx, ep->L, np, np, ep->dinv, t1, t2);
+        gpi_back_solve_vec(ctx, ep->L, np, np, ep->dinv, t2, t1);
+        hipLaunchKernelGGL(ep_w_kernel, g1(np), dim3(256), 0, s, t2, ep->nu(), ep->st(), t1, n, np);    // b = nu - st o z
+        // R = b b^T - S^1/2 (L L^T)^-1 S^1/2 :  (L L^T)^-1 = T T^T with T = L^-T
+        double *T, *Binv;
+        GP_TRY(gpi_ws_get(ctx, WS_VT, sizeof(double) * (size_t)np * np, &T));
+        GP_TRY(gpi_ws_get(ctx, WS_D, sizeof(double) * (size_t)np * np, &Binv));
+        gpi_inverse_transpose_lower(ctx, T, ep->L, np, np, ep->dinv);
+        gpk_gemm_nt(s, np, np, np, 1.0, T, np, T, np, 0.0, Binv, np, 1, 1);
+        hipLaunchKernelGGL(scale_sym_lower_kernel, dim3(8, n), dim3(256), 0, s, Binv, ep->st(), n, np);
+        Kinv = Binv;
+    }
+    gpk_lml_grad_traces(s, dX, n, d, n, theta, t2, Kinv, np, parts, dres);    // g_p = 0.5 tr(R C_p), all P parameters  :60-65
+    return gpi_download_2d(ctx, grad, P, dres, P, P, 1);
 }
 
 gp_status gp_ep_get(gp_ep *ep, int what, double *out, int ld) {

@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256) void lml_grad_trace_kernel(const double *__res
         double w = 0.0;
         if (gi < n && gj < n) {
             const int hi = gi > gj ? gi : gj, lo = gi > gj ? gj : gi;
-            w = ai * alpha[gj] - Kinv[hi + (size_t)lo * ldk];
+            w = ai * alpha[gj] - (Kinv ? Kinv[hi + (size_t)lo * ldk] : 0.0);
             if (gi == gj) tr += w;
         }
         we[q] = wgt * w * exp(-0.5 * r2[q]);

@@ -141,6 +141,11 @@ gp_status gp_ep_sweep(gp_ep *ep, int nsweeps, double *tau, double *nu, int *info
 gp_status gp_ep_set_site_params(gp_ep *ep, const double *tau, const double *nu, int *info);
 /* epMarginalLikelihood :71-96.  strict != 0: as compiled (term at :92 dropped); 0: intended formula. */
 gp_status gp_ep_lml(gp_ep *ep, int strict, double *lml);
+/* MarginalLikelihoodEvaluator.logLikelihoodDerivativesAfterHyperParams, gp/classification/MarginalLikelihoodEvaluator.scala:46-66:
+ * gradient of the EP log marginal likelihood w.r.t. the d+2 ARD-RBF hyper-parameters, for the K this state was created
+ * from (K = Gram(X, theta)).  strict != 0: as compiled (rMatrix = b b^T only, the `- backSolve(..)` line at :59 is a dropped
+ * statement; b = nu - (S^1/2 L) \ (L^T \ (S^1/2 K nu))); strict == 0: Rasmussen & Williams Alg. 5.2. grad[d+2]. */
+gp_status gp_ep_lml_grad_rbf(gp_ep *ep, const double *X, int d, int ldx, const double *theta, int strict, double *grad);
 enum { GP_EP_GET_L = 0, GP_EP_GET_SIGMA = 1, GP_EP_GET_MU = 2, GP_EP_GET_CAV_TAU = 3, GP_EP_GET_CAV_NU = 4 };
 gp_status gp_ep_get(gp_ep *ep, int what, double *out, int ld);
 /* GpClassifier.classify, gp/classification/GpClassifier.scala:24-47: Ks is m x n (test-train),

@@ -335,3 +335,39 @@ def test_ep_argument_errors(ctx):
     with pytest.raises(ValueError):
         ep.predict(np.zeros((2, 10)), np.ones(2))     # classify before trainClassifier
     ep.close()
+
+
+@pytest.mark.parametrize("strict", [True, False])
+def test_ep_lml_gradient_vs_oracle(ctx, strict):   # MarginalLikelihoodEvaluator.scala:46-66 (as compiled / Alg. 5.2)
+    from gp_algos_amd.core import EpClassifierState
+    p, K, y = _ep_problem(150, seed=11)
+    ep = EpClassifierState(ctx, K, y)
+    ep.sweep(3)
+    g = ep.lml_grad_rbf(p["X"], p["theta"], strict=strict)
+    o = orc.ep_estimate(K, y, 3)
+    og = orc.ep_lml_grad(p["X"], p["theta"], K, o["L"], o["tau"], o["nu"], strict=strict)
+    assert g.shape == og.shape == (5,)
+    assert np.max(np.abs(g - og)) <= 1e-7 * np.max(np.abs(og))
+    ep.close()
+
+
+def test_marginal_likelihood_evaluator_mirror(ctx):
+    from gp_algos_amd import set_default_context
+    from gp_algos_amd.gp.classification.ep_parameter_estimator import FixedSweepsStopCriterion
+    from gp_algos_amd.gp.classification.marginal_likelihood_evaluator import (MarginalLikelihoodEvaluator,
+                                                                             MeshHyperParamsLogLikelihoodEvaluator)
+    from gp_algos_amd.utils.kernel_requisites import GaussianRbfKernel, GaussianRbfParams
+    set_default_context(ctx)
+    p, K, y = _ep_problem(80, seed=21)
+    kf = GaussianRbfKernel(GaussianRbfParams(1.0, [1.0, 1.0, 1.0], 0.0))
+    ev = MarginalLikelihoodEvaluator(FixedSweepsStopCriterion(3), kf, strict=True)
+    lml, grad = ev.logLikelihood(p["X"], y, p["theta"])
+    o = orc.ep_estimate(K, y, 3)
+    assert abs(lml - orc.ep_lml(o, y, True)) <= 1e-9 * abs(lml)
+    og = orc.ep_lml_grad(p["X"], p["theta"], K, o["L"], o["tau"], o["nu"], strict=True)
+    assert np.max(np.abs(grad - og)) <= 1e-7 * np.max(np.abs(og))
+    ev2 = MarginalLikelihoodEvaluator(FixedSweepsStopCriterion(3), kf, strict=True)
+    mesh = MeshHyperParamsLogLikelihoodEvaluator(MarginalLikelihoodEvaluator(FixedSweepsStopCriterion(2), kf))
+    settings, vals = mesh.evaluate([[1.0, 1.5], [1.0], [1.2], [0.9, 1.4], [0.0]], p["X"], y)
+    assert len(settings) == 4 and vals.shape == (4,) and np.all(np.isfinite(vals))
+    assert ev2.logLikelihoodWithoutGrad(p["X"], y, p["theta"]) == lml
