@@ -84,9 +84,11 @@ double syrk_flops(int r, int K) { return trapezoid_flops(r, r, K); }
 //   inner (nb = 128), confined to one outer panel of GP_OUTER = 512 columns:
 //       potrf_diag128(Akk) -> Lkk + 16x16 tile inverses;  A21 <- A21 Lkk^-T (MFMA trsm panel, all rows below);
 //       the rest of the OUTER PANEL's columns -= A21 A21^T (narrow MFMA update, K = 128)
-//   outer: trailing matrix -= P P^T with K = 512 (the high-intensity MFMA syrk this design is built around),
-//       split into (a) the next outer panel's columns, on the main stream, and (b) everything to the right
-//       of it, on the side stream, so (b) overlaps the latency-bound factorisation of the next panel.
+//   outer: trailing matrix -= P P^T with K = 512 (the high-intensity MFMA syrk this design is built around), one launch.
+//       Optional (ctx->lookahead, off by default): split into (a) the next outer panel's columns on the main stream
+//       and (b) everything to the right of it on the side stream, overlapping the next panel's factorisation --
+//       measured slower on MI355X (n = 8192: 11.0 vs 10.8 ms, n = 32768: 280 vs 237 ms) because the single-workgroup
+//       diagonal kernel needs a whole CU's LDS and starves behind (b)'s workgroups.
 // `extra` (0 or GP_NB) rows below the matrix ride along: with y^T in row np this leaves (L^-1 y)^T there.
 void chol_blocked(gp_ctx *ctx, double *A, int np, int lda, double *dinv, int extra) {
     hipStream_t s = ctx->stream, s2 = ctx->side;
@@ -146,7 +148,8 @@ void back_solve_vec(gp_ctx *ctx, const double *L, int np, int ldl, const double 
 
 // Vt (mp x np, ld mp) <- Vt * L^-T, block column by block column (forwardSolve(L, K*^T) transposed).
 // sumsq (length mp) accumulates row sums of squares of the result when non-null.
-void solve_rows_lower(gp_ctx *ctx, double *Vt, int mp, const double *L, int np, int ldl, const double *dinv, double *sumsq) {
+void solve_rows_lower(gp_ctx *ctx, double *Vt, int mp, const double *L, int np, int ldl, const double *dinv, double *sumsq,
+                      const double *tvec = nullptr, double *dots = nullptr) {
     hipStream_t s = ctx->stream;
     const int nblk = np / GP_NB;
     // Few rows (mp/128 tiles per step would leave most of the 256 CUs idle): right-looking -- after block column i is
@@ -161,7 +164,8 @@ void solve_rows_lower(gp_ctx *ctx, double *Vt, int mp, const double *L, int np, 
             gp_prof_end(ctx, GP_PROF_GEMM, 2.0 * mp * GP_NB * (double)i * GP_NB);
         }
         gp_prof_begin(ctx, GP_PROF_TRSM);
-        gpk_trsm_panel128(s, Vi, mp, mp, L + (size_t)i * GP_NB + (size_t)i * GP_NB * ldl, ldl, dinv + (size_t)i * GP_NB * 16, sumsq);
+        gpk_trsm_panel128(s, Vi, mp, mp, L + (size_t)i * GP_NB + (size_t)i * GP_NB * ldl, ldl, dinv + (size_t)i * GP_NB * 16, sumsq,
+                          tvec ? tvec + (size_t)i * GP_NB : nullptr, dots);
         gp_prof_end(ctx, GP_PROF_TRSM, (double)mp * GP_NB * GP_NB);
         const int rest = np - (i + 1) * GP_NB;
         if (right_looking && rest > 0) {
@@ -248,10 +252,19 @@ void model_factor(gp_model *m) {
     gpk_pad_identity(s, m->dL, m->n, m->np, m->ldl);
     gpk_copy_strided(s, m->dL + m->np, (size_t)m->ldl, m->dy, 1, m->np);
     chol_blocked(ctx, m->dL, m->np, m->ldl, m->ddinv, GP_NB);
-    double *z = m->dtmp;
-    gpk_copy_strided(s, z, 1, m->dL + m->np, (size_t)m->ldl, m->np);
-    back_solve_vec(ctx, m->dL, m->np, m->ldl, m->ddinv, z, m->dalpha);
-    gpk_lml(s, m->dL, m->n, m->ldl, m->dy, m->dalpha, m->dlml);
+    gpk_copy_strided(s, m->dtmp, 1, m->dL + m->np, (size_t)m->ldl, m->np);     // t = L^-1 y
+    m->alpha_valid = false;
+    gpk_lml(s, m->dL, m->n, m->ldl, m->dtmp, m->dlml);
+}
+
+// alpha = L^-T t, on demand: the posterior (mean = V^T t) and the LML (y.alpha = |t|^2) never need it
+void ensure_alpha(gp_model *m) {
+    if (m->alpha_valid) return;
+    hipStream_t s = m->ctx->stream;
+    double *z = m->dtmp + m->np;
+    (void)hipMemcpyAsync(z, m->dtmp, sizeof(double) * m->np, hipMemcpyDeviceToDevice, s);
+    back_solve_vec(m->ctx, m->dL, m->np, m->ldl, m->ddinv, z, m->dalpha);
+    m->alpha_valid = true;
 }
 
 }  // namespace
@@ -262,7 +275,8 @@ gp_status gpi_upload_2d(gp_ctx *ctx, double *dst, int ldd, const double *src, in
 gp_status gpi_download_2d(gp_ctx *ctx, double *dst, int ldd, const double *src, int lds, int rows, int cols) { return download_2d(ctx, dst, ldd, src, lds, rows, cols); }
 gp_status gpi_read_info(gp_ctx *ctx, int *info) { return read_info(ctx, info); }
 void gpi_chol_blocked(gp_ctx *ctx, double *A, int np, int lda, double *dinv, int extra) { chol_blocked(ctx, A, np, lda, dinv, extra); }
-void gpi_solve_rows_lower(gp_ctx *ctx, double *Vt, int mp, const double *L, int np, int ldl, const double *dinv, double *sumsq) { solve_rows_lower(ctx, Vt, mp, L, np, ldl, dinv, sumsq); }
+void gpi_solve_rows_lower(gp_ctx *ctx, double *Vt, int mp, const double *L, int np, int ldl, const double *dinv, double *sumsq,
+                          const double *tvec, double *dots) { solve_rows_lower(ctx, Vt, mp, L, np, ldl, dinv, sumsq, tvec, dots); }
 void gpi_inverse_transpose_lower(gp_ctx *ctx, double *T, const double *L, int np, int ldl, const double *dinv) { inverse_transpose_lower(ctx, T, L, np, ldl, dinv); }
 void gpi_back_solve_vec(gp_ctx *ctx, const double *L, int np, int ldl, const double *dinv, double *z, double *alpha) { back_solve_vec(ctx, L, np, ldl, dinv, z, alpha); }
 // z <- L^-1 t (t is consumed): one fused launch per block step
@@ -317,7 +331,7 @@ gp_status gp_ctx_create(int device, void *stream, gp_ctx **out) {
     if (e == hipSuccess) e = hipMalloc(&ctx->d_scalars, sizeof(double) * 256);
     if (e == hipSuccess) e = hipMalloc(&ctx->d_info, sizeof(int) * 4);
     if (e == hipSuccess) e = hipMemset(ctx->d_info, 0, sizeof(int) * 4);
-    if (e == hipSuccess && (gpk_init_kernels() != 0 || gpk_init_diag_kernels() != 0)) e = hipErrorInvalidValue;
+    if (e == hipSuccess && gpk_init_diag_kernels() != 0) e = hipErrorInvalidValue;
     if (e != hipSuccess) { delete ctx; return GP_EHIP; }
     *out = ctx;
     return GP_OK;
@@ -594,6 +608,7 @@ gp_status gp_model_get(gp_model *m, int what, double *out, int ld) {
             GP_REQUIRE(ctx, ld >= m->n, "ld < n");
             return download_2d(ctx, out, ld, m->dL, m->ldl, m->n, m->n);
         case GP_GET_ALPHA:
+            ensure_alpha(m);
             return download_2d(ctx, out, m->n, m->dalpha, m->np, m->n, 1);
         case GP_GET_LML:
             return download_2d(ctx, out, 1, m->dlml, 1, 1, 1);
@@ -633,9 +648,12 @@ static gp_status predict_core(gp_model *mdl, const double *dXs, int m, int ldxs,
     gp_prof_begin(ctx, GP_PROF_GRAM);
     gpk_gram_cross(s, dXs, m, ldxs, mdl->dX, n, n, mdl->d, mdl->theta.data(), Vt, mp);
     gp_prof_end(ctx, GP_PROF_GRAM, 8.0 * m * (double)n + 8.0 * (m + n) * mdl->d);
-    gpk_gemv_rows(s, Vt, m, n, mp, mdl->dalpha, dmean, partial, nchunk);
+    // sumsq and the mean accumulate inside the row-panel solves: var = kss - |v|^2, mean = v . (L^-1 y)  (= K* alpha)
+    double *dots = partial;
     GP_HIP(ctx, hipMemsetAsync(sumsq, 0, sizeof(double) * mp, s));
-    solve_rows_lower(ctx, Vt, mp, mdl->dL, np, mdl->ldl, mdl->ddinv, sumsq);
+    GP_HIP(ctx, hipMemsetAsync(dots, 0, sizeof(double) * mp, s));
+    solve_rows_lower(ctx, Vt, mp, mdl->dL, np, mdl->ldl, mdl->ddinv, sumsq, mdl->dtmp, dots);
+    GP_HIP(ctx, hipMemcpyAsync(dmean, dots, sizeof(double) * m, hipMemcpyDeviceToDevice, s));
     if (dvar) {
         const double sf = mdl->theta[0], sn = mdl->theta[mdl->d + 1];
         gpk_var_finish(s, dvar, sumsq, m, sf * sf + sn * sn);
@@ -768,6 +786,7 @@ extern "C" gp_status gp_lml_grad_rbf_batched(gp_ctx *ctx, const double *X, int n
             gp_prof_begin(ctx, GP_PROF_SYRK);
             gpk_gemm_nt(s, np, np, np, 1.0, T, np, T, np, 0.0, Kinv, np, 1, 1);  // Kinv = T T^T, lower
             gp_prof_end(ctx, GP_PROF_SYRK, (double)np * np * np / 3.0);
+            ensure_alpha(m);
             gpk_lml_grad_traces(s, m->dX, n, d, n, theta, m->dalpha, Kinv, np, partials, dres + 1);
         }
         hipError_t e = hipMemcpyAsync(dres, m->dlml, sizeof(double), hipMemcpyDeviceToDevice, s);

@@ -224,7 +224,7 @@ gp_status ep_refactor(gp_ep *ep) {
     double *Vt;
     GP_TRY(gpi_ws_get(ctx, WS_VT, sizeof(double) * (size_t)np * np, &Vt));
     hipLaunchKernelGGL(scale_cols_kernel, dim3(2048), dim3(256), 0, s, Vt, ep->K, ep->st(), np, np, np);
-    gpi_solve_rows_lower(ctx, Vt, np, ep->L, np, np, ep->dinv, nullptr);
+    gpi_solve_rows_lower(ctx, Vt, np, ep->L, np, np, ep->dinv, nullptr, nullptr, nullptr);
     // Sigma = K - Vt Vt^T  (lower on the MFMA syrk, then mirrored)
     gpk_copy_2d(s, ep->Sig, np, ep->K, np, np, np);
     gp_prof_begin(ctx, GP_PROF_SYRK);
@@ -432,7 +432,7 @@ gp_status gp_ep_predict(gp_ep *ep, const double *Ks, int m, int ldks, const doub
     gpk_gemv_rows(s, Vt, m, n, mp, ep->tmp2(), dout, partial, 16);
     hipLaunchKernelGGL(scale_cols_kernel, dim3(1024), dim3(256), 0, s, Vt, Vt, ep->st(), mp, np, mp);
     GP_HIP(ctx, hipMemsetAsync(sumsq, 0, sizeof(double) * mp, s));
-    gpi_solve_rows_lower(ctx, Vt, mp, ep->L, np, np, ep->dinv, sumsq);
+    gpi_solve_rows_lower(ctx, Vt, mp, ep->L, np, np, ep->dinv, sumsq, nullptr, nullptr);
     hipLaunchKernelGGL(ep_prob_kernel, g1(m), dim3(256), 0, s, dout + mp, dout, sumsq, dk, m);
     return gpi_download_2d(ctx, prob, m, dout + mp, m, m, 1);
 }

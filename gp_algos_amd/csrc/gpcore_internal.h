@@ -32,7 +32,8 @@ struct gp_ctx {
     int prof_which = GP_PROF_OFF;
     gp_prof_slot prof[GP_PROF_NCLASSES];
     int num_cu = 256;
-    bool lookahead = true;        // overlap the far trailing update with the next panel (GPCORE_LOOKAHEAD=0 disables)
+    bool lookahead = false;       // GPCORE_LOOKAHEAD=1: run the far trailing update on the side stream, overlapping the next panel.
+                                  // Measured slower at n = 8192..32768 (the 150 KB-LDS diagonal kernel starves behind the GEMM), so off.
     char err[512] = {0};
     // scratch reused across calls
     double *d_scalars = nullptr;  // small device scratch (256 doubles)
@@ -49,7 +50,8 @@ struct gp_model {
     double *dL = nullptr;            // (np + GP_NB) x np, ld = ldl; row np holds y^T -> (L^-1 y)^T
     double *dalpha = nullptr;        // np
     double *ddinv = nullptr;         // np x 16: inverses of the 16x16 diagonal tiles of L
-    double *dtmp = nullptr;          // np: intermediate L^-1 y
+    double *dtmp = nullptr;          // 2 x np: t = L^-1 y (kept), scratch for the backward solve
+    bool alpha_valid = false;        // alpha = L^-T t is computed lazily (predict and the LML only need t)
     double *dlml = nullptr;          // 1 double on device
     std::vector<double> theta;       // d + 2
     double sigma_noise = NAN;
@@ -79,11 +81,6 @@ void gpk_gram_cross(hipStream_t s, const double *Xs, int m, int ldxs, const doub
 void gpk_pad_identity(hipStream_t s, double *A, int n, int np, int lda);
 void gpk_zero_upper(hipStream_t s, double *A, int n, int lda);
 void gpk_fill(hipStream_t s, double *p, size_t count, double v);
-// in-place Cholesky of the 128x128 diagonal block at A (ld lda); first failing pivot (1-based, + base) -> *d_info (if 0).
-void gpk_potrf_diag(hipStream_t s, double *A, int lda, int *d_info, int base);
-// X (M x 128, ldx) <- X * Lkk^{-T}  (rows solved independently by substitution); M multiple of 128.
-// if sumsq != nullptr: sumsq[p] += sum_c X(p,c)^2 accumulated in ascending column order.
-void gpk_trsm_panel(hipStream_t s, double *X, int M, int ldx, const double *Lkk, int ldl, double *sumsq);
 // X (M x 128) <- X * Ukk^{-T} with Ukk UPPER triangular (back substitution per row)
 void gpk_trsm_panel_upper(hipStream_t s, double *X, int M, int ldx, const double *Ukk, int ldu);
 void gpk_transpose(hipStream_t s, double *dst, int ldd, const double *src, int lds, int rows, int cols);
@@ -94,24 +91,21 @@ void gpk_lml_grad_traces(hipStream_t s, const double *X, int n, int d, int ldx, 
 int gpk_lml_grad_partials_size(int n, int d);
 // y (len M) -= A (M x 128, lda) * x (128)
 void gpk_gemv_panel_sub(hipStream_t s, const double *A, int M, int lda, const double *x, double *y);
-// y (len 128) -= A^T x: y[c] -= sum_r A(r,c) x[r], A is M x 128
-void gpk_gemvT_panel_sub(hipStream_t s, const double *A, int M, int lda, const double *x, double *y);
-// solve 128x128 diagonal block: trans=0: L t = b ; trans=1: L^T t = b ; in place on b (len 128)
-void gpk_trsv_diag(hipStream_t s, const double *Lkk, int ldl, double *b, int trans);
 // out[i] = sum_j Ks(i,j) * alpha[j], deterministic, j ascending per row chunk
 void gpk_gemv_rows(hipStream_t s, const double *Ks, int m, int n, int ldks, const double *alpha, double *out, double *partial, int nchunk);
-// lml = -0.5 y.alpha - sum log L_ii - n/2 log 2pi  (n real rows)
-void gpk_lml(hipStream_t s, const double *L, int n, int ldl, const double *y, const double *alpha, double *out);
+// lml = -0.5 t.t - sum log L_ii - n/2 log 2pi with t = L^-1 y  (y.alpha = |L^-1 y|^2; n real rows)
+void gpk_lml(hipStream_t s, const double *L, int n, int ldl, const double *t, double *out);
 // var[i] = kss - sumsq[i]
 void gpk_var_finish(hipStream_t s, double *var, const double *sumsq, int m, double kss);
 void gpk_copy_2d(hipStream_t s, double *dst, int ldd, const double *src, int lds, int rows, int cols);
 double gpk_probe_mfma(hipStream_t s, int num_cu, int waves_per_simd, double *clock_mhz, double *cycles_per_mfma);
-int gpk_init_kernels();
 int gpk_init_diag_kernels();
 // MFMA-blocked critical-path kernels (kernels_diag.hip).  dinv holds the inverses of the 16x16 diagonal
 // tiles of L: tile b (rows 16b..16b+15) at dinv + 256*b, element (c,k) at c + 16k; a 128-block owns 8 tiles.
 void gpk_potrf_diag128(hipStream_t s, double *A, int lda, double *dinv_k, int *d_info, int base);
-void gpk_trsm_panel128(hipStream_t s, double *X, int M, int ldx, const double *Lkk, int ldl, const double *dinv_k, double *sumsq);
+// optional fused row reductions: sumsq[p] += sum_c X(p,c)^2 ; dots[p] += sum_c X(p,c) tvec[c]
+void gpk_trsm_panel128(hipStream_t s, double *X, int M, int ldx, const double *Lkk, int ldl, const double *dinv_k, double *sumsq,
+                       const double *tvec = nullptr, double *dots = nullptr);
 void gpk_fwd_step(hipStream_t s, const double *L, int ldl, const double *dinv_k, double *t, double *sol, int k0, int r);
 void gpk_bwd_step(hipStream_t s, const double *L, int ldl, const double *dinv_k, double *t, double *sol, int k0);
 void gpk_tile_inverses(hipStream_t s, const double *L, int np, int ldl, double *dinv);
@@ -125,7 +119,8 @@ gp_status gpi_upload_2d(gp_ctx *ctx, double *dst, int ldd, const double *src, in
 gp_status gpi_download_2d(gp_ctx *ctx, double *dst, int ldd, const double *src, int lds, int rows, int cols);
 gp_status gpi_read_info(gp_ctx *ctx, int *info);
 void gpi_chol_blocked(gp_ctx *ctx, double *A, int np, int lda, double *dinv, int extra);
-void gpi_solve_rows_lower(gp_ctx *ctx, double *Vt, int mp, const double *L, int np, int ldl, const double *dinv, double *sumsq);
+void gpi_solve_rows_lower(gp_ctx *ctx, double *Vt, int mp, const double *L, int np, int ldl, const double *dinv, double *sumsq,
+                          const double *tvec = nullptr, double *dots = nullptr);
 void gpi_back_solve_vec(gp_ctx *ctx, const double *L, int np, int ldl, const double *dinv, double *z, double *alpha);
 void gpi_inverse_transpose_lower(gp_ctx *ctx, double *T, const double *L, int np, int ldl, const double *dinv);
 void gpi_forward_solve_vec(gp_ctx *ctx, const double *L, int np, int ldl, const double *dinv, double *t, double *z);

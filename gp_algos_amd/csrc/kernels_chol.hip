@@ -1,97 +1,15 @@
-// Latency-bound pieces of the blocked fp64 Cholesky / triangular solves (gfx950):
-//   potrf_diag   : in-LDS Cholesky of one 128x128 diagonal block     (breeze.linalg.cholesky, GpPredictor.scala:120)
-//   trsm_panel   : X <- X * Lkk^-T, one thread per row, substitution  (MatrixUtils.solveTriangular, MatrixUtils.scala:123-133)
-//   trsv / gemv  : alpha = L^T \ (L \ y)                              (GpPredictor.scala:121-122)
-//   gemv_rows    : fMean = K* alpha, column-ascending accumulation     (GpPredictor.scala:33)
-//   lml          : -1/2 y.alpha - sum log L_ii - n/2 log 2 pi          (GpPredictor.scala:144-149)
-// The O(n^3) work lives in kernels_gemm.hip; these kernels sit on the critical path between GEMMs.
+// Vector / reduction kernels around the blocked factorisation (gfx950):
+//   gemv_rows        : fMean = K* alpha, column-ascending accumulation     (GpPredictor.scala:33)
+//   lml              : -1/2 y.alpha - sum log L_ii - n/2 log 2 pi          (GpPredictor.scala:144-149)
+//   lml_grad_trace   : all P traces 0.5 tr((alpha alpha^T - K^-1) dK/dtheta_p) in one pass (GpPredictor.scala:70-78)
+//   trsm_panel_upper : X <- X * U^-T for the backSolve(R, B) entry point    (MatrixUtils.scala:33-35)
+//   transpose, identity, panel gemv helpers
+// The O(n^3) work lives in kernels_gemm.hip, the critical-path diagonal-block kernels in kernels_diag.hip.
 #include "gpcore_internal.h"
 
 namespace {
 
 constexpr int NB = GP_NB;          // 128
-constexpr int LS = NB + 1;         // LDS column stride (doubles) -> conflict-free column sweeps
-
-// ---------------------------------------------------------------------------------------------
-// 128x128 Cholesky in LDS, right-looking, 256 threads.  On a non-positive pivot the first failing
-// 1-based global index is recorded in *info (if still 0) and the block is left partially factored.
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void potrf_diag_kernel(double *__restrict__ A, int lda, int *info, int base) {
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    double *a = sm;               // NB x LS
-    double *col = sm + NB * LS;   // NB
-    const int tid = threadIdx.x;
-    for (int e = tid; e < NB * NB; e += 256) {
-        int i = e & (NB - 1), j = e >> 7;
-        a[i + j * LS] = (i >= j) ? A[i + (size_t)j * lda] : 0.0;
-    }
-    const int i = tid & (NB - 1), half = tid >> 7;
-    bool failed = false;
-    for (int j = 0; j < NB; ++j) {
-        __syncthreads();
-        const double ajj = a[j + j * LS];
-        if (!(ajj > 0.0)) {
-            if (tid == 0) atomicCAS(info, 0, base + j + 1);
-            failed = true;
-            break;
-        }
-        const double djj = sqrt(ajj);
-        if (half == 0 && i >= j) {
-            double v = (i == j) ? djj : a[i + j * LS] / djj;
-            col[i] = v;
-            a[i + j * LS] = v;
-        }
-        __syncthreads();
-        const double li = col[i];
-        for (int c = j + 1 + half; c < NB; c += 2)
-            if (i >= c) a[i + c * LS] = fma(-li, col[c], a[i + c * LS]);
-    }
-    __syncthreads();
-    if (failed) return;
-    for (int e = tid; e < NB * NB; e += 256) {
-        int r = e & (NB - 1), c = e >> 7;
-        A[r + (size_t)c * lda] = (r >= c) ? a[r + c * LS] : 0.0;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// X (M x 128) <- X * L^-T : each row p solves  L x_p^T = b_p^T  by forward substitution in 16-column
-// register chunks.  Earlier chunks of the same row are re-read from global (same thread wrote them),
-// L entries are wave-uniform (scalar loads).  sumsq[p] += sum_c x_pc^2 in ascending c.
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void trsm_panel_kernel(double *__restrict__ X, int M, int ldx,
-                                                        const double *__restrict__ L, int ldl,
-                                                        double *__restrict__ sumsq) {
-    const int p = blockIdx.x * 64 + threadIdx.x;
-    if (p >= M) return;
-    double *xr = X + p;
-    double ss = 0.0;
-    for (int cb = 0; cb < NB; cb += 16) {
-        double acc[16];
-#pragma unroll
-        for (int cc = 0; cc < 16; ++cc) acc[cc] = xr[(size_t)(cb + cc) * ldx];
-        for (int k = 0; k < cb; ++k) {
-            const double xk = xr[(size_t)k * ldx];
-            const double *lk = L + cb + (size_t)k * ldl;
-#pragma unroll
-            for (int cc = 0; cc < 16; ++cc) acc[cc] = fma(-xk, lk[cc], acc[cc]);
-        }
-#pragma unroll
-        for (int cc = 0; cc < 16; ++cc) {
-            const double *lc = L + cb + (size_t)(cb + cc) * ldl;  // column cb+cc, rows cb..
-            const double x = acc[cc] / lc[cc];
-            acc[cc] = x;
-#pragma unroll
-            for (int c2 = cc + 1; c2 < 16; ++c2) acc[c2] = fma(-x, lc[c2], acc[c2]);
-        }
-#pragma unroll
-        for (int cc = 0; cc < 16; ++cc) {
-            xr[(size_t)(cb + cc) * ldx] = acc[cc];
-            ss = fma(acc[cc], acc[cc], ss);
-        }
-    }
-    if (sumsq) sumsq[p] += ss;
-}
 
 // y[p] -= sum_k A(p,k) x[k], A is M x 128
 __global__ __launch_bounds__(256) void gemv_panel_sub_kernel(const double *__restrict__ A, int M, int lda,
@@ -105,54 +23,6 @@ __global__ __launch_bounds__(256) void gemv_panel_sub_kernel(const double *__res
 #pragma unroll 8
     for (int k = 0; k < NB; ++k) acc = fma(A[p + (size_t)k * lda], xs[k], acc);
     y[p] -= acc;
-}
-
-// y[c] -= sum_r A(r,c) x[r], A is M x 128: one workgroup per column, fixed-order tree reduction
-__global__ __launch_bounds__(256) void gemvT_panel_sub_kernel(const double *__restrict__ A, int M, int lda,
-                                                              const double *__restrict__ x, double *__restrict__ y) {
-    __shared__ double red[256];
-    const int c = blockIdx.x;
-    double acc = 0.0;
-    for (int r = threadIdx.x; r < M; r += 256) acc = fma(A[r + (size_t)c * lda], x[r], acc);
-    red[threadIdx.x] = acc;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) y[c] -= red[0];
-}
-
-// 128x128 triangular solve with one right-hand side, in LDS.  trans = 0: L t = b; trans = 1: L^T t = b.
-__global__ __launch_bounds__(128) void trsv_diag_kernel(const double *__restrict__ L, int ldl, double *__restrict__ b, int trans) {
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    double *a = sm;              // NB x LS, a[i + j*LS] = L(i,j)
-    double *v = sm + NB * LS;    // NB
-    const int tid = threadIdx.x;
-    for (int e = tid; e < NB * NB; e += 128) {
-        int i = e & (NB - 1), j = e >> 7;
-        a[i + j * LS] = L[i + (size_t)j * ldl];
-    }
-    v[tid] = b[tid];
-    __syncthreads();
-    if (!trans) {
-        for (int c = 0; c < NB; ++c) {
-            const double xc = v[c] / a[c + c * LS];
-            __syncthreads();
-            if (tid == c) v[c] = xc;
-            else if (tid > c) v[tid] = fma(-a[tid + c * LS], xc, v[tid]);
-            __syncthreads();
-        }
-    } else {
-        for (int c = NB - 1; c >= 0; --c) {
-            const double xc = v[c] / a[c + c * LS];
-            __syncthreads();
-            if (tid == c) v[c] = xc;
-            else if (tid < c) v[tid] = fma(-a[c + tid * LS], xc, v[tid]);
-            __syncthreads();
-        }
-    }
-    b[tid] = v[tid];
 }
 
 // partial[chunk][i] = sum_{j in chunk} Ks(i,j) alpha[j]  (j ascending); then out[i] = sum_chunk partial (ascending)
@@ -177,12 +47,12 @@ __global__ void reduce_chunks_kernel(const double *__restrict__ partial, int m, 
     out[i] = acc;
 }
 
-__global__ __launch_bounds__(1024) void lml_kernel(const double *__restrict__ L, int n, int ldl, const double *__restrict__ y,
-                                                   const double *__restrict__ alpha, double *__restrict__ out) {
+__global__ __launch_bounds__(1024) void lml_kernel(const double *__restrict__ L, int n, int ldl, const double *__restrict__ tv,
+                                                   double *__restrict__ out) {
     __shared__ double r1[1024], r2[1024];
     double d = 0.0, lg = 0.0;
     for (int i = threadIdx.x; i < n; i += 1024) {
-        d = fma(y[i], alpha[i], d);
+        d = fma(tv[i], tv[i], d);
         lg += log(L[i + (size_t)i * ldl]);
     }
     r1[threadIdx.x] = d;
@@ -420,40 +290,16 @@ void gpk_lml_grad_traces(hipStream_t s, const double *X, int n, int d, int ldx, 
     hipLaunchKernelGGL(lml_grad_reduce_kernel, dim3(d + 2), dim3(256), 0, s, partials, nblocks, d + 2, sc, out);
 }
 
-int gpk_init_kernels() {
-    // > 64 KiB of dynamic LDS needs an explicit opt-in per kernel
-    const int lds = (int)((NB * LS + NB) * sizeof(double));
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(potrf_diag_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(trsv_diag_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    return e == hipSuccess ? 0 : 1;
-}
-
-void gpk_potrf_diag(hipStream_t s, double *A, int lda, int *d_info, int base) {
-    size_t lds = (size_t)(NB * LS + NB) * sizeof(double);
-    hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), lds, s, A, lda, d_info, base);
-}
-void gpk_trsm_panel(hipStream_t s, double *X, int M, int ldx, const double *Lkk, int ldl, double *sumsq) {
-    if (M <= 0) return;
-    hipLaunchKernelGGL(trsm_panel_kernel, dim3((M + 63) / 64), dim3(64), 0, s, X, M, ldx, Lkk, ldl, sumsq);
-}
 void gpk_gemv_panel_sub(hipStream_t s, const double *A, int M, int lda, const double *x, double *y) {
     if (M <= 0) return;
     hipLaunchKernelGGL(gemv_panel_sub_kernel, dim3((M + 255) / 256), dim3(256), 0, s, A, M, lda, x, y);
-}
-void gpk_gemvT_panel_sub(hipStream_t s, const double *A, int M, int lda, const double *x, double *y) {
-    if (M <= 0) return;
-    hipLaunchKernelGGL(gemvT_panel_sub_kernel, dim3(NB), dim3(256), 0, s, A, M, lda, x, y);
-}
-void gpk_trsv_diag(hipStream_t s, const double *Lkk, int ldl, double *b, int trans) {
-    size_t lds = (size_t)(NB * LS + NB) * sizeof(double);
-    hipLaunchKernelGGL(trsv_diag_kernel, dim3(1), dim3(128), lds, s, Lkk, ldl, b, trans);
 }
 void gpk_gemv_rows(hipStream_t s, const double *Ks, int m, int n, int ldks, const double *alpha, double *out, double *partial, int nchunk) {
     hipLaunchKernelGGL(gemv_rows_kernel, dim3((m + 255) / 256, nchunk), dim3(256), 0, s, Ks, m, n, ldks, alpha, partial, nchunk);
     hipLaunchKernelGGL(reduce_chunks_kernel, dim3((m + 255) / 256), dim3(256), 0, s, partial, m, nchunk, out);
 }
-void gpk_lml(hipStream_t s, const double *L, int n, int ldl, const double *y, const double *alpha, double *out) {
-    hipLaunchKernelGGL(lml_kernel, dim3(1), dim3(1024), 0, s, L, n, ldl, y, alpha, out);
+void gpk_lml(hipStream_t s, const double *L, int n, int ldl, const double *t, double *out) {
+    hipLaunchKernelGGL(lml_kernel, dim3(1), dim3(1024), 0, s, L, n, ldl, t, out);
 }
 void gpk_var_finish(hipStream_t s, double *var, const double *sumsq, int m, double kss) {
     hipLaunchKernelGGL(var_finish_kernel, dim3((m + 255) / 256), dim3(256), 0, s, var, sumsq, m, kss);

@@ -202,7 +202,8 @@ __device__ __forceinline__ void trsm_chunk(double *xs, int sp, int fr, int fg, c
 }
 
 __global__ __launch_bounds__(256, 2) void trsm_panel128_kernel(double *__restrict__ X, int ldx, const double *__restrict__ L, int ldl,
-                                                             const double *__restrict__ dinv, double *__restrict__ sumsq) {
+                                                             const double *__restrict__ dinv, double *__restrict__ sumsq,
+                                                             const double *__restrict__ tvec, double *__restrict__ dots) {
     extern __shared__ __attribute__((aligned(16))) double xs[];   // NB x XS
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
@@ -242,6 +243,12 @@ __global__ __launch_bounds__(256, 2) void trsm_panel128_kernel(double *__restric
 #pragma unroll
     for (int q = 0; q < 16; ++q)
         *reinterpret_cast<double2_t *>(Xg + li + (size_t)(lc + 8 * q) * ldx) = *reinterpret_cast<const double2_t *>(xs + (lc + 8 * q) * XS + li);
+    if (dots && tid < 64) {   // fused row dot with this block's slice of t = L^-1 y: the posterior mean  V^T (L^-1 y)
+        double acc = 0.0;
+#pragma unroll 8
+        for (int c = 0; c < NB; ++c) acc = fma(xs[c * XS + tid], tvec[c], acc);
+        dots[row0 + tid] += acc;
+    }
     if (sumsq) {
         ss += __shfl_xor(ss, 16);
         ss += __shfl_xor(ss, 32);
@@ -370,9 +377,10 @@ int gpk_init_diag_kernels() {
 void gpk_potrf_diag128(hipStream_t s, double *A, int lda, double *dinv, int *d_info, int base) {
     hipLaunchKernelGGL(potrf_diag128_kernel, dim3(1), dim3(256), POTRF_LDS, s, A, lda, dinv, d_info, base);
 }
-void gpk_trsm_panel128(hipStream_t s, double *X, int M, int ldx, const double *Lkk, int ldl, const double *dinv, double *sumsq) {
+void gpk_trsm_panel128(hipStream_t s, double *X, int M, int ldx, const double *Lkk, int ldl, const double *dinv, double *sumsq,
+                       const double *tvec, double *dots) {
     if (M <= 0) return;
-    hipLaunchKernelGGL(trsm_panel128_kernel, dim3(M / 64), dim3(256), TRSM_LDS, s, X, ldx, Lkk, ldl, dinv, sumsq);
+    hipLaunchKernelGGL(trsm_panel128_kernel, dim3(M / 64), dim3(256), TRSM_LDS, s, X, ldx, Lkk, ldl, dinv, sumsq, tvec, dots);
 }
 void gpk_fwd_step(hipStream_t s, const double *L, int ldl, const double *dinv_k, double *t, double *sol, int k0, int r) {
     int grid = r > 0 ? (r + 255) / 256 : 1;
