@@ -245,7 +245,7 @@ def main():
                          "flops_per_launch_avg": g_work / max(g_k, 1)},
             "cholesky": {"fit_ms": t_fit * 1e3, "total_tflops": (n ** 3 / 3.0) / t_fit / 1e12,
                          "trailing_update_tflops": syrk_tflops, "trailing_update_frac_of_peak": syrk_tflops / PEAK_FP64_MFMA_TFLOPS,
-                         "trailing_update_launches": s_k, "panel_width": 128},
+                         "trailing_update_launches": s_k, "panel_width_inner": 128, "trailing_update_K": 512},
             "gram": {"GBps": r_work / (r_ms * 1e-3) / 1e9 if r_ms > 0 else 0.0, "frac_of_hbm_peak": (r_work / (r_ms * 1e-3) / 1e9) / PEAK_HBM_GBS if r_ms > 0 else 0.0},
             "predict_only_points_per_s": m / t_pred, "predict_ms": t_pred * 1e3,
             "mfma_f64_probe_tflops": probe,
