@@ -7,10 +7,11 @@
 //   - K^-1 = L^-T L^-1 for the LML gradient              (GpPredictor.scala:66-67)
 //   - EP  Sigma = K - V^T V                               (EpParameterEstimator.scala:60)
 //
-// Design (CDNA4): 128x128 output tile per 256-thread workgroup (4 waves, 2x2, 64x64 per wave =
-// 4x4 v_mfma_f64_16x16x4_f64 accumulators = 128 acc VGPRs), BK = 16, LDS double-buffered and
-// register-staged.  Both operands are "row-contiguous" in memory (column-major, NT form), so one
-// wave-load of 64 x 16 B covers a full 1 KiB tile column: perfectly coalesced.  LDS image is
+// Design (CDNA4): 128x128 output tile per workgroup of 8 waves (2 x 4, 64x32 per wave = 4x2
+// v_mfma_f64_16x16x4_f64 accumulators; a 4-wave 64x64-per-wave variant is kept for A/B runs), BK = 16,
+// LDS double-buffered and filled by LDS-DMA (global_load_lds_dwordx4, no staging VGPRs, no ds_write
+// pass).  Both operands are "row-contiguous" in memory (column-major, NT form), so one wave
+// instruction of 64 x 16 B moves a full 1 KiB tile column: perfectly coalesced.  LDS image is
 // [k][row] with a row stride of 144 doubles (1152 B = 128 mod 256 B), which makes the
 // ds_read_b64 fragment reads (lanes 0-15: 16 rows at k, lanes 16-31: the same rows at k+1)
 // bank-conflict free.  The MFMA is issued with the B-fragment as srcA and the A-fragment as srcB
@@ -57,8 +58,8 @@ __device__ __forceinline__ void tile_coords_lower(int t, int nbm, int nbn, int &
     bi = bj = 0;   // not reached for a valid launch
 }
 
-template <int LOWER, int HAS_BETA>
-__global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(int M, int N, int K, double alpha, const double *__restrict__ A, int lda,
+template <int LOWER, int HAS_BETA, int NW>
+__global__ __launch_bounds__(NW * 64, NW / 2) void gemm_nt_f64_kernel(int M, int N, int K, double alpha, const double *__restrict__ A, int lda,
                                                            const double *__restrict__ B, int ldb, double beta,
                                                            double *__restrict__ C, int ldc, int ktri) {
     __shared__ __attribute__((aligned(16))) double smem[2 * 2 * TK * LDS_STRIDE];
@@ -85,76 +86,57 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(int M, int N, int K
     }
     const int row0 = bi * TM, col0 = bj * TN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = (wave & 1) * 64, wn = (wave >> 1) * 64;
+    constexpr int NT = (NW == 8) ? 2 : 4;          // 16-column accumulator tiles per wave (8 waves: 64 x 32 per wave)
+    const int wm = (wave & 1) * 64, wn = (wave >> 1) * (NT * 16);
 
     // ktri: A(i,k) == 0 for k < i (e.g. L^-T): the product over k can start at this tile's row block
     const int kbeg = ktri ? row0 : 0;
     const double *Ag = A + row0 + (size_t)kbeg * lda;
     const double *Bg = B + col0 + (size_t)kbeg * ldb;
 
-    // staging map: 4 x (16-byte) loads per thread per operand.  e = tid + 256*q: row pair e&63, k = e>>6
-    const int ld_r = (tid & 63) * 2;
-    const int ld_k = tid >> 6;  // + 4*q
-
-    double4_t acc[4][4];
+    double4_t acc[NT][4];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < NT; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
 
-    double2_t ra[4], rb[4];
     const int KT = (K - kbeg) / TK;
-
-    if (KT > 0) {
+    // Staging: LDS-DMA (global_load_lds_dwordx4).  One wave instruction moves 64 lanes x 16 B = one full k-row of the
+    // tile (128 doubles = 1 KiB, contiguous in LDS; the 16-double pad follows it), so the lane-linear destination rule
+    // is met with the padded image.  No staging VGPRs, no ds_write pass; wave w fetches k-rows w, w+NW, ...
+    const double *Asrc = Ag + lane * 2 + (size_t)wave * lda;
+    const double *Bsrc = Bg + lane * 2 + (size_t)wave * ldb;
+    auto stage = [&](int buf, int kt) {
+        const size_t koff = (size_t)kt * TK;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            ra[q] = *reinterpret_cast<const double2_t *>(Ag + ld_r + (size_t)(ld_k + 4 * q) * lda);
-            rb[q] = *reinterpret_cast<const double2_t *>(Bg + ld_r + (size_t)(ld_k + 4 * q) * ldb);
+        for (int q = 0; q < TK / NW; ++q) {
+            __builtin_amdgcn_global_load_lds(Asrc + (koff + NW * q) * lda, As + (buf * TK + wave + NW * q) * LDS_STRIDE, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(Bsrc + (koff + NW * q) * ldb, Bs + (buf * TK + wave + NW * q) * LDS_STRIDE, 16, 0, 0);
         }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            *reinterpret_cast<double2_t *>(As + (ld_k + 4 * q) * LDS_STRIDE + ld_r) = ra[q];
-            *reinterpret_cast<double2_t *>(Bs + (ld_k + 4 * q) * LDS_STRIDE + ld_r) = rb[q];
-        }
-    }
+    };
+    if (KT > 0) stage(0, 0);
     __syncthreads();
 
     const int fr = lane & 15, fk = lane >> 4;
     for (int kt = 0; kt < KT; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < KT) {
-            const size_t koff = (size_t)(kt + 1) * TK;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                ra[q] = *reinterpret_cast<const double2_t *>(Ag + ld_r + (koff + ld_k + 4 * q) * lda);
-                rb[q] = *reinterpret_cast<const double2_t *>(Bg + ld_r + (koff + ld_k + 4 * q) * ldb);
-            }
-        }
+        if (kt + 1 < KT) stage(cur ^ 1, kt + 1);
         const double *Ac = As + cur * TK * LDS_STRIDE + wm + fr;
         const double *Bc = Bs + cur * TK * LDS_STRIDE + wn + fr;
 #pragma unroll
         for (int ks = 0; ks < TK / 4; ++ks) {
-            double af[4], bf[4];
+            double af[4], bf[NT];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                af[t] = Ac[(ks * 4 + fk) * LDS_STRIDE + t * 16];
-                bf[t] = Bc[(ks * 4 + fk) * LDS_STRIDE + t * 16];
-            }
+            for (int t = 0; t < 4; ++t) af[t] = Ac[(ks * 4 + fk) * LDS_STRIDE + t * 16];
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
+            for (int t = 0; t < NT; ++t) bf[t] = Bc[(ks * 4 + fk) * LDS_STRIDE + t * 16];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt)
                     acc[nt][mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[nt], af[mt], acc[nt][mt], 0, 0, 0);
         }
-        if (kt + 1 < KT) {
-            const int nxt = cur ^ 1;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                *reinterpret_cast<double2_t *>(As + nxt * TK * LDS_STRIDE + (ld_k + 4 * q) * LDS_STRIDE + ld_r) = ra[q];
-                *reinterpret_cast<double2_t *>(Bs + nxt * TK * LDS_STRIDE + (ld_k + 4 * q) * LDS_STRIDE + ld_r) = rb[q];
-            }
-        }
-        __syncthreads();
+        __syncthreads();   // drains the DMA of tile kt+1 (vmcnt) and fences the reads of tile kt
     }
 
     // epilogue: acc[nt][mt][r] = D[n = wn + nt*16 + fk + 4r][m = wm + mt*16 + fr].
@@ -162,7 +144,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(int M, int N, int K
     // element (what a naive `v += beta * *cp` compiles to) serialises 64 memory round trips per tile.
     const bool diag_tile = LOWER && (bi == bj);
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
+    for (int nt = 0; nt < NT; ++nt) {
         double cv[4][4];
         if (HAS_BETA) {
 #pragma unroll
@@ -224,16 +206,19 @@ void gpk_gemm_nt(hipStream_t s, int M, int N, int K, double alpha, const double 
                  double beta, double *C, int ldc, int lower, int ktri) {
     if (M <= 0 || N <= 0) return;
     const bool hb = beta != 0.0;
-    if (lower) {
-        int nbm = M / TM, nbn = N / TN;   // trapezoid: M >= N
-        int ntiles = nbn * nbm - nbn * (nbn - 1) / 2;
-        if (hb) hipLaunchKernelGGL((gemm_nt_f64_kernel<1, 1>), dim3(ntiles), dim3(256), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, ktri);
-        else hipLaunchKernelGGL((gemm_nt_f64_kernel<1, 0>), dim3(ntiles), dim3(256), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, ktri);
+    // 8 waves per workgroup (64 x 32 per wave, 4 waves/SIMD at 2 workgroups/CU) measured equal to 4 waves (64 x 64 per wave) on
+    // long-K launches (65 TFLOP/s both) and ~5 % better on the short-K Cholesky updates; GPCORE_GEMM_WAVES=4 selects the other.
+    static const int nw = [] { const char *e = getenv("GPCORE_GEMM_WAVES"); return (e && atoi(e) == 4) ? 4 : 8; }();
+    const int ntiles = lower ? ((N / TN) * (M / TM) - (N / TN) * ((N / TN) - 1) / 2) : (M / TM) * (N / TN);   // lower: trapezoid, M >= N
+#define GP_LAUNCH(LO, HB, NWV) hipLaunchKernelGGL((gemm_nt_f64_kernel<LO, HB, NWV>), dim3(ntiles), dim3(NWV * 64), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, ktri)
+    if (nw == 8) {
+        if (lower) { if (hb) GP_LAUNCH(1, 1, 8); else GP_LAUNCH(1, 0, 8); }
+        else { if (hb) GP_LAUNCH(0, 1, 8); else GP_LAUNCH(0, 0, 8); }
     } else {
-        int ntiles = (M / TM) * (N / TN);
-        if (hb) hipLaunchKernelGGL((gemm_nt_f64_kernel<0, 1>), dim3(ntiles), dim3(256), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, ktri);
-        else hipLaunchKernelGGL((gemm_nt_f64_kernel<0, 0>), dim3(ntiles), dim3(256), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, ktri);
+        if (lower) { if (hb) GP_LAUNCH(1, 1, 4); else GP_LAUNCH(1, 0, 4); }
+        else { if (hb) GP_LAUNCH(0, 1, 4); else GP_LAUNCH(0, 0, 4); }
     }
+#undef GP_LAUNCH
 }
 
 double gpk_probe_mfma(hipStream_t s, int num_cu, int waves_per_simd, double *clock_mhz, double *cycles_per_mfma) {
