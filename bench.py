@@ -124,9 +124,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--n", type=int, default=8192)
-    ap.add_argument("--d", type=int, default=8)
-    ap.add_argument("--m", type=int, default=65536)
+    ap.add_argument("--train-n", dest="n", type=int, default=8192)
+    ap.add_argument("--dim", dest="d", type=int, default=8)
+    ap.add_argument("--test-points", dest="m", type=int, default=65536)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4"],
                     help="c2 (default, the BASELINE.json metric): fit + posterior; c3: batched LML+gradient over 64 settings; "
@@ -141,11 +141,18 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
+    # Rehearsal knobs for a 1-GPU box only (never set by the driver): run several ranks on one device over gloo.
+    if os.environ.get("GPCORE_BENCH_DEVICE") is not None:
+        local_rank = int(os.environ["GPCORE_BENCH_DEVICE"])
+    backend = os.environ.get("GPCORE_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import __graft_entry__ as entry
     entry.build()
@@ -196,7 +203,7 @@ def main():
     s_k, s_ms, s_work = ctx.profile_read(L.GP_PROF_SYRK)
     r_k, r_ms, r_work = ctx.profile_read(L.GP_PROF_GRAM)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 

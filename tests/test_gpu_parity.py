@@ -371,3 +371,73 @@ def test_marginal_likelihood_evaluator_mirror(ctx):
     settings, vals = mesh.evaluate([[1.0, 1.5], [1.0], [1.2], [0.9, 1.4], [0.0]], p["X"], y)
     assert len(settings) == 4 and vals.shape == (4,) and np.all(np.isfinite(vals))
     assert ev2.logLikelihoodWithoutGrad(p["X"], y, p["theta"]) == lml
+
+
+# ---- edge cases: empty / ragged / maximum feature count / strided views ---------------------------
+def test_empty_inputs(ctx):
+    K = ctx.gram_rbf(np.zeros((0, 3)), [1.0, 1.0, 1.0, 1.0, 0.1])
+    assert K.shape == (0, 0)
+    assert ctx.cross_gram_rbf(np.zeros((0, 2)), np.zeros((5, 2)), [1.0, 1.0, 1.0, 0.1]).shape == (0, 5)
+    assert ctx.potrf_lower(np.zeros((0, 0))).shape == (0, 0)
+    from gp_algos_amd.core import RegressionModel
+    p = _problem(30, 2, 0)
+    mdl = RegressionModel(ctx, p["X"], p["y"], p["theta"])
+    mean, var, cov = mdl.predict(np.zeros((0, 2)), full_cov=True)
+    assert mean.shape == (0,) and var.shape == (0,) and cov.shape == (0, 0)
+    lml, grad, info = ctx.lml_grad_batched(p["X"], p["y"], np.zeros((0, 4)))
+    assert lml.shape == (0,)
+    mdl.close()
+
+
+def test_maximum_feature_count_and_rejects_beyond(ctx):
+    p = _problem(70, 64, 9, seed=2, scale=6.0)
+    K = ctx.gram_rbf(p["X"], p["theta"])
+    assert np.max(np.abs(K - orc.gram_sym(p["X"], p["theta"])) / np.abs(K)) <= TOL_GRAM
+    with pytest.raises(ValueError):
+        ctx.gram_rbf(np.zeros((4, 65)), np.ones(67))
+
+
+def test_strided_views_through_the_c_abi(ctx):
+    """Breeze views cross the boundary (GpPredictorTest.scala:66 passes trainData(0 to -3, ::)): ld > rows."""
+    import ctypes as C
+    from gp_algos_amd import _lib as L
+    n, d, ld = 50, 3, 64
+    p = _problem(ld, d, 0, seed=8)
+    buf = np.asfortranarray(p["X"])                       # ld x d, the view is its first n rows
+    theta = L.f64(p["theta"])
+    K = np.full((ld, n), 7.0, order="F")                  # output with ldk = ld > n
+    st = ctx._lib.gp_gram_rbf(ctx.h, L.dptr(buf), n, d, ld, L.dptr(theta), L.dptr(K), ld, L.GP_FULL)
+    ctx.check(st)
+    Ko = orc.gram_sym(buf[:n], p["theta"])
+    assert np.max(np.abs(K[:n] - Ko) / np.abs(Ko)) <= TOL_GRAM
+    assert np.all(K[n:] == 7.0)                           # rows outside the view untouched
+    A = np.full((ld, n), -3.0, order="F")
+    A[:n] = Ko
+    info = C.c_int()
+    ctx.check(ctx._lib.gp_potrf_lower(ctx.h, L.dptr(A), n, ld, C.byref(info)))
+    Lo = orc.cholesky_lower(Ko)
+    assert np.max(np.abs(A[:n] - Lo)) <= 1e-11 and np.all(A[n:] == -3.0)
+    h = C.c_void_p()
+    ctx.check(ctx._lib.gp_fit_rbf(ctx.h, L.dptr(buf), n, d, ld, L.dptr(p["y"][:n].copy()), L.dptr(theta), float("nan"), C.byref(h), C.byref(info)))
+    alpha = np.zeros(n)
+    ctx.check(ctx._lib.gp_model_get(h, L.GP_GET_ALPHA, L.dptr(alpha), n))
+    _, ao = orc.fit(buf[:n], p["y"][:n], p["theta"])
+    assert np.max(np.abs(alpha - ao)) <= 1e-8 * np.max(np.abs(ao))
+    ctx._lib.gp_model_destroy(h)
+
+
+def test_ill_conditioned_but_pd_problem(ctx):
+    """Tiny noise, long length-scales: kappa(K) ~ 1e9.  The factorisation residual must stay at the rounding level and
+    downstream quantities agree with the oracle to the tolerance its conditioning allows."""
+    from gp_algos_amd.core import RegressionModel
+    p = synth.regression(300, 2, 20, 31, 32, 33, np.array([2.0, 3.0, 3.0, 1e-3]))
+    mdl = RegressionModel(ctx, p["X"], p["y"], p["theta"])
+    K = orc.gram_sym(p["X"], p["theta"])
+    L = mdl.L()
+    assert np.linalg.norm(L @ L.T - K) / np.linalg.norm(K) <= TOL_CHOL
+    Lo, ao = orc.fit(p["X"], p["y"], p["theta"])
+    mean, var, _ = mdl.predict(p["Xs"])
+    om, ov, _, _ = orc.predict(p["X"], p["theta"], Lo, ao, p["Xs"])
+    assert np.max(np.abs(mean - om)) <= 1e-5 and np.max(np.abs(var - ov)) <= 1e-6
+    assert abs(mdl.lml() - orc.lml(Lo, ao, p["y"])) <= 1e-9 * abs(mdl.lml())
+    mdl.close()
