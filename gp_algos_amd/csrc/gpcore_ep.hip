@@ -83,26 +83,41 @@ __global__ __launch_bounds__(128) void ep_block_kernel(int n, int np, int i0, in
     for (int t = 0; t < bsz; ++t) {
         if (r < t) w[r] = cs[r] * Sb[t + r * LS];
         __syncthreads();
-        double sp = A[r + t * LS];
-        for (int q = 0; q < t; ++q) sp = fma(-w[q], Sb[r + q * LS], sp);
+        // four partial sums break the dependent FMA chain (t <= 127 terms)
+        double p0 = A[r + t * LS], p1 = 0.0, p2 = 0.0, p3 = 0.0;
+        int q = 0;
+        for (; q + 4 <= t; q += 4) {
+            p0 = fma(-w[q], Sb[r + q * LS], p0);
+            p1 = fma(-w[q + 1], Sb[r + (q + 1) * LS], p1);
+            p2 = fma(-w[q + 2], Sb[r + (q + 2) * LS], p2);
+            p3 = fma(-w[q + 3], Sb[r + (q + 3) * LS], p3);
+        }
+        for (; q < t; ++q) p0 = fma(-w[q], Sb[r + q * LS], p0);
+        const double sp = (p0 + p1) + (p2 + p3);
         Sb[r + t * LS] = sp;
         if (r == t) {
+            // Site update, EpParameterEstimator.scala:45-53 + marginalMoments :98-109, with the divisions folded:
+            // the reference's 12 divisions and 2 square roots become 4 reciprocals and one rsqrt (this scalar chain is
+            // the critical path of a sweep: one lane, 4096 times).  Same formulas, re-associated; fp64 throughout.
             const int i = i0 + t;
             const double sii = sp, mui = mb[t];
             const double to = tau[i], no = nu[i];
-            const double tc = 1.0 / sii - to;                      // :45
-            const double nc = mui / sii - no;                      // :46
-            const double cm = nc / tc, cvr = 1.0 / tc;             // marginalMoments(ni/tau, 1/tau, y) :47-48
-            const int yi = y[i];
-            const double temp = sqrt(1.0 + cvr);
-            const double z = (yi * cm) / temp;
-            const double dz = dnorm_d(z), pz = pnorm_d(z);
-            const double mi_hat = cm + (yi * cvr * dz) / (pz * temp);
-            const double sg_hat = cvr - ((cvr * cvr * dz) * (z + dz / pz)) / ((1.0 + cvr) * pz);
-            const double dtau = 1.0 / sg_hat - tc - to;            // :49
-            const double tn = to + dtau;                           // :50
-            const double nn = mi_hat / sg_hat - nc;                // :51
-            const double c = 1.0 / (1.0 / dtau + sii);             // :53
+            const double rs = 1.0 / sii;
+            const double tc = rs - to;                              // cavity tau  :45
+            const double nc = mui * rs - no;                        // cavity nu   :46
+            const double cvr = 1.0 / tc;                            // cavity variance 1/tau
+            const double cm = nc * cvr;                             // cavity mean
+            const double yi = (double)y[i];
+            const double rt = rsqrt(1.0 + cvr);                     // 1/sqrt(1 + sigma^2)
+            const double z = (yi * cm) * rt;
+            const double ratio = dnorm_d(z) / pnorm_d(z);           // phi(z)/Phi(z)
+            const double mi_hat = cm + (yi * cvr) * (ratio * rt);
+            const double sg_hat = cvr - (cvr * cvr) * (ratio * (z + ratio)) * (rt * rt);
+            const double isg = 1.0 / sg_hat;
+            const double dtau = isg - tc - to;                      // :49
+            const double tn = to + dtau;                            // :50
+            const double nn = mi_hat * isg - nc;                    // :51
+            const double c = dtau / fma(dtau, sii, 1.0);            // 1/(1/dtau + sii), finite at dtau = 0  :53
             const double dnu = nn - no;
             const double coef = dnu - c * (mui + dnu * sii);
             sc[0] = coef;
