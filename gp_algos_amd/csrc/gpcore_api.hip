@@ -3,7 +3,9 @@
 #include "gpcore_internal.h"
 
 #include <algorithm>
+#include <atomic>
 #include <new>
+#include <thread>
 
 // ------------------------------------------------------------------------------------------------
 // profiling: HIP events on the context's stream around one kernel class
@@ -29,7 +31,7 @@ namespace {
 
 struct ws_slot { void *p = nullptr; size_t bytes = 0; };
 
-struct ctx_ext { ws_slot ws[WS_COUNT]; };
+struct ctx_ext { ws_slot ws[WS_COUNT]; std::vector<gp_ctx *> children; };
 
 // gp_ctx owns a ctx_ext through this side table (keeps the header struct POD-ish)
 ctx_ext *ext_of(gp_ctx *ctx);
@@ -344,6 +346,9 @@ void gp_ctx_destroy(gp_ctx *ctx) {
     for (int c = 0; c < GP_PROF_NCLASSES; ++c)
         for (hipEvent_t e : ctx->prof[c].ev) (void)hipEventDestroy(e);
     ctx_ext *x = ext_of(ctx);
+    for (gp_ctx *c : x->children) gp_ctx_destroy(c);
+    x->children.clear();
+    (void)hipSetDevice(ctx->device);
     for (int i = 0; i < WS_COUNT; ++i) if (x->ws[i].p) (void)hipFree(x->ws[i].p);
     if (ctx->d_scalars) (void)hipFree(ctx->d_scalars);
     if (ctx->d_info) (void)hipFree(ctx->d_info);
@@ -756,6 +761,62 @@ static gp_status trsm_impl(gp_ctx *ctx, int trans, const double *L, int n, int l
 //   fit -> (L, alpha, LML);  T = L^-T (rows of I solved against L);  Kinv = T T^T (MFMA syrk, k >= row block);
 //   fused traces over W = alpha alpha^T - Kinv.
 // ------------------------------------------------------------------------------------------------
+namespace {
+
+// one worker = one context (own stream + workspaces) + one resident model; evaluates settings pulled from a shared counter
+struct lml_worker {
+    gp_ctx *ctx = nullptr;
+    gp_model *m = nullptr;
+    double *T = nullptr, *Kinv = nullptr, *partials = nullptr, *dres = nullptr;
+    gp_status st = GP_OK;
+};
+
+gp_status lml_worker_setup(lml_worker &w, const double *X, int n, int d, int ldx, const double *y, int nparams) {
+    gp_ctx *ctx = w.ctx;
+    GP_HIP(ctx, hipSetDevice(ctx->device));
+    GP_TRY(model_alloc(ctx, n, d, true, &w.m));
+    GP_TRY(upload_2d(ctx, w.m->dX, n, X, ldx, n, d));
+    GP_TRY(upload_2d(ctx, w.m->dy, n, y, n, n, 1));
+    const int np = w.m->np, P = d + 2;
+    if (nparams > 0) {
+        GP_TRY(ws_get(ctx, WS_VT, sizeof(double) * (size_t)np * np, &w.T));
+        GP_TRY(ws_get(ctx, WS_D, sizeof(double) * (size_t)np * np, &w.Kinv));
+        GP_TRY(ws_get(ctx, WS_PARTIAL, sizeof(double) * (size_t)gpk_lml_grad_partials_size(n, d), &w.partials));
+    }
+    GP_TRY(ws_get(ctx, WS_C, sizeof(double) * (size_t)(P + 1), &w.dres));
+    return GP_OK;
+}
+
+gp_status lml_worker_eval(lml_worker &w, const double *theta, int nparams, double sigma_noise, double *lml, double *grad, int *info) {
+    gp_ctx *ctx = w.ctx;
+    gp_model *m = w.m;
+    hipStream_t s = ctx->stream;
+    const int np = m->np, n = m->n, d = m->d, P = d + 2;
+    GP_TRY(gp_model_refit_dev(m, theta, sigma_noise));
+    if (nparams > 0) {
+        inverse_transpose_lower(ctx, w.T, m->dL, np, m->ldl, m->ddinv);          // T = L^-T (upper triangular)
+        gp_prof_begin(ctx, GP_PROF_SYRK);
+        gpk_gemm_nt(s, np, np, np, 1.0, w.T, np, w.T, np, 0.0, w.Kinv, np, 1, 1);  // Kinv = T T^T, lower
+        gp_prof_end(ctx, GP_PROF_SYRK, (double)np * np * np / 3.0);
+        ensure_alpha(m);
+        gpk_lml_grad_traces(s, m->dX, n, d, n, theta, m->dalpha, w.Kinv, np, w.partials, w.dres + 1);
+    }
+    double host[66 + 1];
+    GP_HIP(ctx, hipMemcpyAsync(w.dres, m->dlml, sizeof(double), hipMemcpyDeviceToDevice, s));
+    GP_HIP(ctx, hipMemcpyAsync(host, w.dres, sizeof(double) * (P + 1), hipMemcpyDeviceToHost, s));
+    int h = 0;
+    GP_TRY(read_info(ctx, &h));   // also syncs the stream
+    if (info) *info = h;
+    *lml = h ? NAN : host[0];
+    for (int p = 0; p < nparams; ++p) grad[p] = h ? NAN : host[1 + p];
+    return GP_OK;
+}
+
+}  // namespace
+
+// Settings are independent: a few of them are kept in flight at once, each on its own stream (own context, own host
+// thread issuing the launches), so the latency-bound diagonal-block chain of one setting overlaps the GEMMs of another.
+// GPCORE_LML_WORKERS (default 6, 1 for n > 12288) sets how many; results do not depend on it.
 extern "C" gp_status gp_lml_grad_rbf_batched(gp_ctx *ctx, const double *X, int n, int d, int ldx, const double *y, const double *thetas,
                                              int B, int nparams, double sigma_noise, double *lml, double *grad, int *info) {
     if (!ctx) return GP_EINVAL;
@@ -764,43 +825,41 @@ extern "C" gp_status gp_lml_grad_rbf_batched(gp_ctx *ctx, const double *X, int n
     const int P = d + 2;
     GP_REQUIRE(ctx, nparams >= 0 && nparams <= P && (nparams == 0 || grad), "0 <= nparams <= d+2");
     if (B == 0) return GP_OK;
-    GP_HIP(ctx, hipSetDevice(ctx->device));
-    gp_model *m = nullptr;
-    GP_TRY(model_alloc(ctx, n, d, true, &m));
-    gp_status st = upload_2d(ctx, m->dX, n, X, ldx, n, d);
-    if (st == GP_OK) st = upload_2d(ctx, m->dy, n, y, n, n, 1);
-    const int np = m->np;
-    double *T = nullptr, *Kinv = nullptr, *partials = nullptr, *dres = nullptr;
-    if (st == GP_OK) st = ws_get(ctx, WS_VT, sizeof(double) * (size_t)np * np, &T);
-    if (st == GP_OK) st = ws_get(ctx, WS_D, sizeof(double) * (size_t)np * np, &Kinv);
-    if (st == GP_OK) st = ws_get(ctx, WS_PARTIAL, sizeof(double) * (size_t)gpk_lml_grad_partials_size(n, d), &partials);
-    if (st == GP_OK) st = ws_get(ctx, WS_C, sizeof(double) * (size_t)(P + 1), &dres);
-    hipStream_t s = ctx->stream;
-    std::vector<double> host(P + 1);
-    for (int b = 0; b < B && st == GP_OK; ++b) {
-        const double *theta = thetas + (size_t)b * P;
-        st = gp_model_refit_dev(m, theta, sigma_noise);
-        if (st != GP_OK) break;
-        if (nparams > 0) {
-            inverse_transpose_lower(ctx, T, m->dL, np, m->ldl, m->ddinv);     // T = L^-T (upper triangular)
-            gp_prof_begin(ctx, GP_PROF_SYRK);
-            gpk_gemm_nt(s, np, np, np, 1.0, T, np, T, np, 0.0, Kinv, np, 1, 1);  // Kinv = T T^T, lower
-            gp_prof_end(ctx, GP_PROF_SYRK, (double)np * np * np / 3.0);
-            ensure_alpha(m);
-            gpk_lml_grad_traces(s, m->dX, n, d, n, theta, m->dalpha, Kinv, np, partials, dres + 1);
-        }
-        hipError_t e = hipMemcpyAsync(dres, m->dlml, sizeof(double), hipMemcpyDeviceToDevice, s);
-        if (e == hipSuccess) e = hipMemcpyAsync(host.data(), dres, sizeof(double) * (P + 1), hipMemcpyDeviceToHost, s);
-        if (e != hipSuccess) { GP_SET_ERR(ctx, "copy results: %s", hipGetErrorString(e)); st = GP_EHIP; break; }
-        int h = 0;
-        st = read_info(ctx, &h);  // also syncs the stream
-        if (st != GP_OK) break;
-        if (info) info[b] = h;
-        lml[b] = h ? NAN : host[0];
-        for (int p = 0; p < nparams; ++p) grad[(size_t)b * nparams + p] = h ? NAN : host[1 + p];
+    int nw = (n > 12288) ? 1 : 6;
+    if (const char *e = getenv("GPCORE_LML_WORKERS")) nw = atoi(e);
+    nw = std::max(1, std::min(std::min(nw, 8), B));
+    // helper contexts are cached on the caller's context
+    ctx_ext *x = ext_of(ctx);
+    while ((int)x->children.size() < nw - 1) {
+        gp_ctx *c = nullptr;
+        if (gp_ctx_create(ctx->device, nullptr, &c) != GP_OK) break;
+        x->children.push_back(c);
     }
-    gp_model_destroy(m);
-    return st;
+    nw = std::min(nw, (int)x->children.size() + 1);
+    std::vector<lml_worker> ws(nw);
+    for (int k = 0; k < nw; ++k) ws[k].ctx = (k == 0) ? ctx : x->children[k - 1];
+    std::atomic<int> next{0};
+    auto run = [&](int k) {
+        lml_worker &w = ws[k];
+        w.st = lml_worker_setup(w, X, n, d, ldx, y, nparams);
+        while (w.st == GP_OK) {
+            const int b = next.fetch_add(1);
+            if (b >= B) break;
+            w.st = lml_worker_eval(w, thetas + (size_t)b * P, nparams, sigma_noise, lml + b, grad ? grad + (size_t)b * nparams : nullptr,
+                                   info ? info + b : nullptr);
+        }
+        if (w.m) { gp_model_destroy(w.m); w.m = nullptr; }
+    };
+    std::vector<std::thread> threads;
+    for (int k = 1; k < nw; ++k) threads.emplace_back(run, k);
+    run(0);
+    for (auto &t : threads) t.join();
+    for (int k = 0; k < nw; ++k)
+        if (ws[k].st != GP_OK) {
+            if (k > 0) GP_SET_ERR(ctx, "%s", ws[k].ctx->err);
+            return ws[k].st;
+        }
+    return GP_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
