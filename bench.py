@@ -92,6 +92,42 @@ def run_secondary(args):
                                                      "settings sharded %d per GPU" % (B, n, args.d, hi - lo), "B": B, "n": n},
                               "approx_tflops_per_gpu": flops * (hi - lo) * args.steps / dt / 1e12,
                               "lml_first": float(lml[0]), "all_pd": bool(np.all(info == 0))}), flush=True)
+    elif args.workload == "c5":
+        import ctypes as C
+        n = args.n if args.n != 8192 else 32768
+        m = args.m if args.m != 65536 else 131072          # 1M test points / 8 GPUs, rounded to the batch size
+        p = synth.config_c5(n, args.d, 0)
+        i = (np.arange(m, dtype=np.uint64) + np.uint64(rank * m))[:, None]
+        k = np.arange(args.d, dtype=np.uint64)[None, :]
+        Xs = np.asfortranarray(-2.0 + 4.0 * synth.u(43, i * np.uint64(args.d) + k))
+        lib = ctx._lib
+        dX, dy, dXs = ctx.upload(p["X"]), ctx.upload(p["y"]), ctx.upload(Xs)
+        dmean, dvar = ctx.dev_alloc(8 * m), ctx.dev_alloc(8 * m)
+        theta = L.f64(p["theta"])
+        h, info = C.c_void_p(), C.c_int()
+        t0 = time.perf_counter()
+        ctx.check(lib.gp_fit_rbf_dev(ctx.h, dX, n, args.d, n, dy, L.dptr(theta), float("nan"), C.byref(h), C.byref(info)), info.value)
+        ctx.sync()
+        t_fit = time.perf_counter() - t0
+        for _ in range(max(args.warmup, 1)):
+            ctx.check(lib.gp_predict_dev(h, dXs, m, m, dmean, dvar))
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            ctx.check(lib.gp_predict_dev(h, dXs, m, m, dmean, dvar))
+        fence()
+        dt = gdist.max_over_ranks(time.perf_counter() - t0, device="cuda")
+        if rank == 0:
+            var = ctx.download(dvar, (m,))
+            print(json.dumps({"metric": "posterior variances/sec at n=%d fp64 (L resident)" % n, "value": world * m * args.steps / dt,
+                              "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 1),
+                              "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                              "dtype": "f64", "data": "synthetic",
+                              "config": {"workload": "C5: n=%d d=%d fit once per GPU (first fit incl. allocation %.0f ms), %d test points per GPU "
+                                                     "per step in batches of 65536" % (n, args.d, t_fit * 1e3, m), "n": n, "m_per_gpu": m},
+                              "tflops_n2m": float(n) * n * m * args.steps / dt / 1e12 * world,
+                              "var_range": [float(var.min()), float(var.max())]}), flush=True)
+        lib.gp_model_destroy(h)
     else:
         n = args.n if args.n != 8192 else 4096
         sweeps = 50
@@ -128,9 +164,9 @@ def main():
     ap.add_argument("--dim", dest="d", type=int, default=8)
     ap.add_argument("--test-points", dest="m", type=int, default=65536)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4"],
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5"],
                     help="c2 (default, the BASELINE.json metric): fit + posterior; c3: batched LML+gradient over 64 settings; "
-                         "c4: EP classification sweeps")
+                         "c4: EP classification sweeps; c5: n=32768 fit once, then 10^6/8 test-point variances per GPU per step")
     args = ap.parse_args()
     if args.workload != "c2":
         return run_secondary(args)
