@@ -54,7 +54,7 @@ __device__ __forceinline__ double pnorm_d(double x) { return 0.5 * (1.0 + erf(x 
 // so the 128 x 128 diagonal block of Sigma0, the block of S and mu live in LDS for the whole block.  Outputs: the new
 // site/cavity parameters, c, -coef, and Lmat = I + strict_lower(S_blk diag(c)) -- the unit-lower factor with which the
 // full-height columns follow afterwards from ONE row-panel solve,  S = Sigma0[:, blk] Lmat^-T  (trsm_panel128).
-__global__ __launch_bounds__(128) void ep_block_kernel(int n, int np, int i0, int bsz, const double *__restrict__ Sig0,
+__global__ __launch_bounds__(192) void ep_block_kernel(int n, int np, int i0, int bsz, const double *__restrict__ Sig0,
                                                        const double *__restrict__ mu, const int *__restrict__ y,
                                                        double *__restrict__ tau, double *__restrict__ nu,
                                                        double *__restrict__ cav_tau, double *__restrict__ cav_nu,
@@ -64,75 +64,89 @@ __global__ __launch_bounds__(128) void ep_block_kernel(int n, int np, int i0, in
     constexpr int LS = GP_NB + 1;
     double *A = sm;                  // column c: Sigma0[blk, i0+c] until site c is processed, afterwards s_c[blk]
     double *Sb = sm;                 //   (the delayed column replaces the Sigma0 column it was built from)
-    double *w = sm + GP_NB * LS;     // c_q * S[i_t, q]
-    double *cs = w + GP_NB;          // c
+    double *cs = sm + GP_NB * LS;    // c
     double *mb = cs + GP_NB;         // mu restricted to the block
-    double *sc = mb + GP_NB;         // scalars: [0] coef
-    const int r = threadIdx.x;
+    double *sc = mb + GP_NB;         // scalars: [0] coef of the current site
+    const int tid = threadIdx.x, r = tid;          // waves 0,1: one block row per thread; wave 2: the site arithmetic
+    const bool rowthread = tid < GP_NB;
+    if (rowthread) {
 #pragma unroll
-    for (int c0 = 0; c0 < GP_NB; c0 += 16) {   // 16 loads in flight per thread (a load/wait/store loop would cost ~100 us)
-        double v[16];
+        for (int c0 = 0; c0 < GP_NB; c0 += 16) {   // 16 loads in flight per thread (a load/wait/store loop would cost ~100 us)
+            double v[16];
 #pragma unroll
-        for (int c = 0; c < 16; ++c) v[c] = Sig0[(i0 + r) + (size_t)(i0 + c0 + c) * np];
+            for (int c = 0; c < 16; ++c) v[c] = Sig0[(i0 + r) + (size_t)(i0 + c0 + c) * np];
 #pragma unroll
-        for (int c = 0; c < 16; ++c) A[r + (c0 + c) * LS] = v[c];
+            for (int c = 0; c < 16; ++c) A[r + (c0 + c) * LS] = v[c];
+        }
+        mb[r] = (i0 + r < n) ? mu[i0 + r] : 0.0;
+        cs[r] = 0.0;
     }
-    mb[r] = (i0 + r < n) ? mu[i0 + r] : 0.0;
-    cs[r] = 0.0;
     __syncthreads();
+    // Software pipeline over the sites of the block.  At the top of iteration t column t already holds s_t and mb is
+    // current through site t-1.  While ONE lane of wave 2 runs the scalar site update t (the serial chain: erf, exp,
+    // reciprocals), waves 0-1 build every term of s_{t+1} that does not depend on it (q < t); after the barrier they add
+    // the q = t term, update mu, and publish column t+1.
     for (int t = 0; t < bsz; ++t) {
-        if (r < t) w[r] = cs[r] * Sb[t + r * LS];
-        __syncthreads();
-        // four partial sums break the dependent FMA chain (t <= 127 terms)
-        double p0 = A[r + t * LS], p1 = 0.0, p2 = 0.0, p3 = 0.0;
-        int q = 0;
-        for (; q + 4 <= t; q += 4) {
-            p0 = fma(-w[q], Sb[r + q * LS], p0);
-            p1 = fma(-w[q + 1], Sb[r + (q + 1) * LS], p1);
-            p2 = fma(-w[q + 2], Sb[r + (q + 2) * LS], p2);
-            p3 = fma(-w[q + 3], Sb[r + (q + 3) * LS], p3);
+        double part = 0.0;
+        if (!rowthread) {
+            if (tid == GP_NB) {
+                // Site update, EpParameterEstimator.scala:45-53 + marginalMoments :98-109, with the divisions folded:
+                // the reference's 12 divisions and 2 square roots become 4 reciprocals and one rsqrt.  Same formulas,
+                // re-associated; fp64 throughout.
+                const int i = i0 + t;
+                const double sii = Sb[t + t * LS], mui = mb[t];
+                const double to = tau[i], no = nu[i];
+                const double rs = 1.0 / sii;
+                const double tc = rs - to;                              // cavity tau  :45
+                const double nc = mui * rs - no;                        // cavity nu   :46
+                const double cvr = 1.0 / tc;                            // cavity variance 1/tau
+                const double cm = nc * cvr;                             // cavity mean
+                const double yi = (double)y[i];
+                const double rt = rsqrt(1.0 + cvr);                     // 1/sqrt(1 + sigma^2)
+                const double z = (yi * cm) * rt;
+                const double ratio = dnorm_d(z) / pnorm_d(z);           // phi(z)/Phi(z)
+                const double mi_hat = cm + (yi * cvr) * (ratio * rt);
+                const double sg_hat = cvr - (cvr * cvr) * (ratio * (z + ratio)) * (rt * rt);
+                const double isg = 1.0 / sg_hat;
+                const double dtau = isg - tc - to;                      // :49
+                const double tn = to + dtau;                            // :50
+                const double nn = mi_hat * isg - nc;                    // :51
+                const double c = dtau / fma(dtau, sii, 1.0);            // 1/(1/dtau + sii), finite at dtau = 0  :53
+                const double dnu = nn - no;
+                const double coef = dnu - c * (mui + dnu * sii);
+                sc[0] = coef;
+                cs[t] = c;
+                tau[i] = tn; nu[i] = nn; cav_tau[i] = tc; cav_nu[i] = nc;
+                cvec[t] = c;
+                ncoef[t] = -coef;
+            }
+        } else if (t + 1 < bsz) {
+            double p0 = A[r + (t + 1) * LS], p1 = 0.0, p2 = 0.0, p3 = 0.0;
+            int q = 0;
+            for (; q + 4 <= t; q += 4) {
+                p0 = fma(-(cs[q] * Sb[(t + 1) + q * LS]), Sb[r + q * LS], p0);
+                p1 = fma(-(cs[q + 1] * Sb[(t + 1) + (q + 1) * LS]), Sb[r + (q + 1) * LS], p1);
+                p2 = fma(-(cs[q + 2] * Sb[(t + 1) + (q + 2) * LS]), Sb[r + (q + 2) * LS], p2);
+                p3 = fma(-(cs[q + 3] * Sb[(t + 1) + (q + 3) * LS]), Sb[r + (q + 3) * LS], p3);
+            }
+            for (; q < t; ++q) p0 = fma(-(cs[q] * Sb[(t + 1) + q * LS]), Sb[r + q * LS], p0);
+            part = (p0 + p1) + (p2 + p3);
         }
-        for (; q < t; ++q) p0 = fma(-w[q], Sb[r + q * LS], p0);
-        const double sp = (p0 + p1) + (p2 + p3);
-        Sb[r + t * LS] = sp;
-        if (r == t) {
-            // Site update, EpParameterEstimator.scala:45-53 + marginalMoments :98-109, with the divisions folded:
-            // the reference's 12 divisions and 2 square roots become 4 reciprocals and one rsqrt (this scalar chain is
-            // the critical path of a sweep: one lane, 4096 times).  Same formulas, re-associated; fp64 throughout.
-            const int i = i0 + t;
-            const double sii = sp, mui = mb[t];
-            const double to = tau[i], no = nu[i];
-            const double rs = 1.0 / sii;
-            const double tc = rs - to;                              // cavity tau  :45
-            const double nc = mui * rs - no;                        // cavity nu   :46
-            const double cvr = 1.0 / tc;                            // cavity variance 1/tau
-            const double cm = nc * cvr;                             // cavity mean
-            const double yi = (double)y[i];
-            const double rt = rsqrt(1.0 + cvr);                     // 1/sqrt(1 + sigma^2)
-            const double z = (yi * cm) * rt;
-            const double ratio = dnorm_d(z) / pnorm_d(z);           // phi(z)/Phi(z)
-            const double mi_hat = cm + (yi * cvr) * (ratio * rt);
-            const double sg_hat = cvr - (cvr * cvr) * (ratio * (z + ratio)) * (rt * rt);
-            const double isg = 1.0 / sg_hat;
-            const double dtau = isg - tc - to;                      // :49
-            const double tn = to + dtau;                            // :50
-            const double nn = mi_hat * isg - nc;                    // :51
-            const double c = dtau / fma(dtau, sii, 1.0);            // 1/(1/dtau + sii), finite at dtau = 0  :53
-            const double dnu = nn - no;
-            const double coef = dnu - c * (mui + dnu * sii);
-            sc[0] = coef;
-            cs[t] = c;
-            tau[i] = tn; nu[i] = nn; cav_tau[i] = tc; cav_nu[i] = nc;
-            cvec[t] = c;
-            ncoef[t] = -coef;
+        __syncthreads();
+        if (rowthread) {
+            const double st = Sb[r + t * LS];
+            const double wt = cs[t] * Sb[(t + 1 < GP_NB ? t + 1 : t) + t * LS];   // c_t * S[i_{t+1}, t]
+            mb[r] = fma(st, sc[0], mb[r]);
+            // column t+1 of the Sigma0 block was only ever read by its own row thread (above), so it can be replaced now
+            if (t + 1 < bsz) Sb[r + (t + 1) * LS] = fma(-wt, st, part);
         }
         __syncthreads();
-        mb[r] = fma(sp, sc[0], mb[r]);
     }
-    if (r >= bsz) { cvec[r] = 0.0; ncoef[r] = 0.0; }
-    __syncthreads();
-    for (int c = 0; c < GP_NB; ++c)
-        Lmat[r + (size_t)c * GP_NB] = (r == c) ? 1.0 : ((r > c && c < bsz) ? Sb[r + c * LS] * cs[c] : 0.0);
+    if (rowthread) {
+        if (r >= bsz) { cvec[r] = 0.0; ncoef[r] = 0.0; }
+        for (int c = 0; c < GP_NB; ++c)
+            Lmat[r + (size_t)c * GP_NB] = (r == c) ? 1.0 : ((r > c && c < bsz) ? Sb[r + c * LS] * cs[c] : 0.0);
+    }
 }
 
 __global__ void scale_cols_kernel(double *__restrict__ dst, const double *__restrict__ src, const double *__restrict__ c, int rows, int cols, int ld) {
@@ -310,7 +324,7 @@ gp_status gp_ep_sweep(gp_ep *ep, int nsweeps, double *tau, double *nu, int *info
             const int bsz = (n - i0 < GP_NB) ? n - i0 : GP_NB;
             double *Lmat = ep->blk, *bdinv = ep->blk + GP_NB * GP_NB;
             double *ncoef = ep->cvec + GP_NB;
-            hipLaunchKernelGGL(ep_block_kernel, dim3(1), dim3(GP_NB), EP_BLOCK_LDS, s, n, np, i0, bsz, ep->Sig, ep->mu(), ep->y,
+            hipLaunchKernelGGL(ep_block_kernel, dim3(1), dim3(192), EP_BLOCK_LDS, s, n, np, i0, bsz, ep->Sig, ep->mu(), ep->y,
                                ep->tau(), ep->nu(), ep->cav_tau(), ep->cav_nu(), ep->cvec, ncoef, Lmat);
             // full-height delayed columns S = Sigma0[:, blk] Lmat^-T, then mu += S coef for every row
             gpk_copy_2d(s, ep->S, np, ep->Sig + (size_t)i0 * np, np, np, GP_NB);
