@@ -232,7 +232,7 @@ __global__ __launch_bounds__(1024) void ep_lml_kernel(int n, int np, const doubl
     red[threadIdx.x] = acc;
     __syncthreads();
     for (int s = 512; s > 0; s >>= 1) {
-        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
         __syncthreads();
     }
     if (threadIdx.x == 0) out[0] = red[0];

@@ -59,7 +59,7 @@ __global__ __launch_bounds__(1024) void lml_kernel(const double *__restrict__ L,
     r2[threadIdx.x] = lg;
     __syncthreads();
     for (int s = 512; s > 0; s >>= 1) {
-        if (threadIdx.x < s) { r1[threadIdx.x] += r1[threadIdx.x + s]; r2[threadIdx.x] += r2[threadIdx.x + s]; }
+        if ((int)threadIdx.x < s) { r1[threadIdx.x] += r1[threadIdx.x + s]; r2[threadIdx.x] += r2[threadIdx.x + s]; }
         __syncthreads();
     }
     if (threadIdx.x == 0) out[0] = -0.5 * r1[0] - r2[0] - 0.5 * (double)n * log(2.0 * M_PI);
@@ -148,7 +148,7 @@ __device__ __forceinline__ double block_sum_256(double v, double *red) {
     red[threadIdx.x] = v;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
-        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
         __syncthreads();
     }
     double r = red[0];
