@@ -159,9 +159,9 @@ __global__ void scale_cols_kernel(double *__restrict__ dst, const double *__rest
 
 // B = I + (st st^T) o K on the lower triangle (EpParameterEstimator.scala:56-58); pad rows have st = 0
 __global__ void ep_bmat_kernel(double *__restrict__ B, const double *__restrict__ K, const double *__restrict__ st, int np) {
-    const int j = blockIdx.y;
-    for (int i = j + blockIdx.x * blockDim.x + threadIdx.x; i < np; i += gridDim.x * blockDim.x)
-        B[i + (size_t)j * np] = (i == j ? 1.0 : 0.0) + (st[i] * st[j]) * K[i + (size_t)j * np];
+    for (int j = blockIdx.y; j < np; j += gridDim.y)
+        for (int i = j + blockIdx.x * blockDim.x + threadIdx.x; i < np; i += gridDim.x * blockDim.x)
+            B[i + (size_t)j * np] = (i == j ? 1.0 : 0.0) + (st[i] * st[j]) * K[i + (size_t)j * np];
 }
 
 __global__ void mirror_lower_kernel(double *__restrict__ A, int np) {
@@ -195,8 +195,8 @@ __global__ void vec_sub_kernel(double *__restrict__ out, const double *__restric
 }
 // M(i,j) = st_i * M(i,j) * st_j on the lower triangle
 __global__ void scale_sym_lower_kernel(double *__restrict__ M, const double *__restrict__ st, int n, int ld) {
-    const int j = blockIdx.y;
-    for (int i = j + blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) M[i + (size_t)j * ld] *= st[i] * st[j];
+    for (int j = blockIdx.y; j < n; j += gridDim.y)
+        for (int i = j + blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) M[i + (size_t)j * ld] *= st[i] * st[j];
 }
 __global__ void vec_mul_kernel(double *__restrict__ out, const double *__restrict__ a, const double *__restrict__ b, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -247,7 +247,7 @@ gp_status ep_refactor(gp_ep *ep) {
     hipStream_t s = ctx->stream;
     const int n = ep->n, np = ep->np;
     hipLaunchKernelGGL(vec_sqrt_kernel, g1(np), dim3(256), 0, s, ep->st(), ep->tau(), n, np);
-    hipLaunchKernelGGL(ep_bmat_kernel, dim3(8, np), dim3(256), 0, s, ep->L, ep->K, ep->st(), np);
+    hipLaunchKernelGGL(ep_bmat_kernel, dim3(8, np < 65535 ? np : 65535), dim3(256), 0, s, ep->L, ep->K, ep->st(), np);
     gpi_chol_blocked(ctx, ep->L, np, np, ep->dinv, 0);   // strict upper triangle of ep->L stays zero from allocation
     // Vt = (K S^1/2) L^-T  (= V^T, V = L \ (S^1/2 K)); kept in the workspace
     double *Vt;
@@ -412,7 +412,7 @@ gp_status gp_ep_lml_grad_rbf(gp_ep *ep, const double *X, int d, int ldx, const d
         GP_TRY(gpi_ws_get(ctx, WS_D, sizeof(double) * (size_t)np * np, &Binv));
         gpi_inverse_transpose_lower(ctx, T, ep->L, np, np, ep->dinv);
         gpk_gemm_nt(s, np, np, np, 1.0, T, np, T, np, 0.0, Binv, np, 1, 1);
-        hipLaunchKernelGGL(scale_sym_lower_kernel, dim3(8, n), dim3(256), 0, s, Binv, ep->st(), n, np);
+        hipLaunchKernelGGL(scale_sym_lower_kernel, dim3(8, n < 65535 ? n : 65535), dim3(256), 0, s, Binv, ep->st(), n, np);
         Kinv = Binv;
     }
     gpk_lml_grad_traces(s, dX, n, d, n, theta, t2, Kinv, np, parts, dres);    // g_p = 0.5 tr(R C_p), all P parameters  :60-65

@@ -104,10 +104,10 @@ __global__ void pad_identity_kernel(double *A, int n, int np, int lda) {
     }
 }
 
-__global__ void zero_upper_kernel(double *A, int lda) {
-    // one grid row (blockIdx.y) per column j; threads sweep the rows i < j (coalesced)
-    const int j = blockIdx.y;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < j; i += gridDim.x * blockDim.x) A[i + (size_t)j * lda] = 0.0;
+__global__ void zero_upper_kernel(double *A, int n, int lda) {
+    // grid rows (blockIdx.y, strided: gridDim.y is capped at 65535) walk the columns j; threads sweep the rows i < j (coalesced)
+    for (int j = blockIdx.y; j < n; j += gridDim.y)
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < j; i += gridDim.x * blockDim.x) A[i + (size_t)j * lda] = 0.0;
 }
 
 __global__ void fill_kernel(double *p, size_t count, double v) {
@@ -158,7 +158,7 @@ void gpk_pad_identity(hipStream_t s, double *A, int n, int np, int lda) {
 
 void gpk_zero_upper(hipStream_t s, double *A, int n, int lda) {
     if (n < 2) return;
-    hipLaunchKernelGGL(zero_upper_kernel, dim3(8, n), dim3(256), 0, s, A, lda);
+    hipLaunchKernelGGL(zero_upper_kernel, dim3(8, n < 65535 ? n : 65535), dim3(256), 0, s, A, n, lda);
 }
 
 void gpk_fill(hipStream_t s, double *p, size_t count, double v) {
