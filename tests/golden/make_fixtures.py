@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Regenerates tests/golden/*.  Run in the build container (needs /root/reference for the data files).
 
-1. boston.csv / bostonPredResults_head.txt: DATA files the reference ships under src/main/resources
+1. boston.csv / cancer.csv / bostonPredResults_head.txt: DATA files the reference ships under src/main/resources
    (inputs of its GpPredictorTest and a stored posterior dump); copied verbatim -- data, not source.
 2. oracle_vectors.json: small seeded problems with the CPU oracle's outputs (fit / predict / LML /
    gradient / EP).  The JVM reference cannot run here (no JDK), so these vectors are
@@ -23,6 +23,7 @@ REF = "/root/reference/src/main/resources"
 def main():
     if os.path.isdir(REF):
         shutil.copyfile(os.path.join(REF, "boston.csv"), os.path.join(HERE, "boston.csv"))
+        shutil.copyfile(os.path.join(REF, "cancer.csv"), os.path.join(HERE, "cancer.csv"))
         with open(os.path.join(REF, "boston", "bostonPredResults.txt")) as f, \
                 open(os.path.join(HERE, "bostonPredResults_head.txt"), "w") as g:
             for k, line in enumerate(f):

@@ -167,3 +167,43 @@ def test_gp_classifier_train_and_classify():
     assert np.max(np.abs(probs2 - oprob2)) <= 1e-8
     acc = np.mean((probs > 0.5) == (Xs[:, 0] + 0.5 * Xs[:, 1] > 0))
     assert acc > 0.8
+
+
+def _load_cancer():
+    """IOUtilities.csvFileToDenseMatrix("cancer.csv") (utils/IOUtilities.scala:13-29): rows that fail to parse ('?') are
+    silently skipped; CancerClassificationTest.scala:57-62 maps label 2 -> -1, else +1 and drops the id column."""
+    rows = []
+    for line in open(os.path.join(GOLD, "cancer.csv")):
+        try:
+            rows.append([float(v) for v in line.strip().split(",") if v != ""])
+        except ValueError:
+            pass
+    data = np.array(rows)
+    y = np.where(data[:, -1] == 2.0, -1, 1).astype(np.int32)
+    return np.asfortranarray(data[:, 1:-1]), y
+
+
+def test_ep_classifier_on_the_reference_cancer_data():
+    """The reference's classification 'tests' are main() programs on cancer.csv with stale one-length-scale parameters
+    (SURVEY.md section 4); here the same data runs through the mirrored classes with a 9-dimensional ARD kernel and is
+    checked against the oracle (site parameters, probabilities) plus a held-out accuracy sanity bound."""
+    from gp_algos_amd.gp.classification.ep_parameter_estimator import FixedSweepsStopCriterion
+    from gp_algos_amd.gp.classification.gp_classifier import AfterEstimationClassifierInput, ClassifierInput, GpClassifier
+    from gp_algos_amd.utils import matrix_utils as MU
+    from gp_algos_amd.utils.kernel_requisites import GaussianRbfKernel, GaussianRbfParams
+    X, y = _load_cancer()
+    assert X.shape == (683, 9)                      # 699 rows, 16 with '?' skipped
+    ntr = 500
+    k = GaussianRbfKernel(GaussianRbfParams(3.0, [12.0] * 9, 0.1))
+    K, Ks, Kss = MU.buildKernelMatrix(k, X[:ntr]), MU.buildKernelMatrix(k, X[ntr:], X[:ntr]), MU.buildKernelMatrix(k, X[ntr:])
+    clf = GpClassifier(FixedSweepsStopCriterion(3))
+    site, L = clf.trainClassifier(ClassifierInput(trainKernelMatrix=K, targets=y[:ntr]))
+    o = orc.ep_estimate(K, y[:ntr], 3)
+    assert np.max(np.abs(site.tauSiteParams - o["tau"])) <= 1e-7 * np.max(np.abs(o["tau"]))
+    assert np.max(np.abs(site.niSiteParams - o["nu"])) <= 1e-7 * np.max(np.abs(o["nu"]))
+    probs = clf.classify(AfterEstimationClassifierInput(targets=y[:ntr], learnParams=(site, L), hyperParams=None,
+                                                        trainKernelMatrix=K, testTrainKernelMatrix=Ks, testKernelMatrix=Kss))
+    oprob, _, _ = orc.ep_classify(K, o["L"], o["tau"], o["nu"], Ks, np.diag(Kss).copy())
+    assert np.max(np.abs(probs - oprob)) <= 1e-8
+    acc = np.mean((probs > 0.5) == (y[ntr:] == 1))
+    assert acc > 0.93
