@@ -92,9 +92,18 @@ double syrk_flops(int r, int K) { return trapezoid_flops(r, r, K); }
 //       measured slower on MI355X (n = 8192: 11.0 vs 10.8 ms, n = 32768: 280 vs 237 ms) because the single-workgroup
 //       diagonal kernel needs a whole CU's LDS and starves behind (b)'s workgroups.
 // `extra` (0 or GP_NB) rows below the matrix ride along: with y^T in row np this leaves (L^-1 y)^T there.
-void chol_blocked(gp_ctx *ctx, double *A, int np, int lda, double *dinv, int extra) {
+// count > 1: a lockstep batch -- problem g lives at A + g*strideA, dinv + g*strideDinv, info + g; every launch covers all of them.
+void chol_blocked(gp_ctx *ctx, double *A, int np, int lda, double *dinv, int extra, int count = 1, size_t strideA = 0, size_t strideDinv = 0,
+                  int *info = nullptr) {
     hipStream_t s = ctx->stream, s2 = ctx->side;
     const int rows = np + extra;
+    if (!info) info = ctx->d_info;
+    gp_batch bdiag, btrsm, bgemm;
+    bdiag.count = btrsm.count = bgemm.count = count;
+    bdiag.s0 = strideA, bdiag.s1 = strideDinv;
+    btrsm.s0 = strideA, btrsm.s1 = strideA, btrsm.s2 = strideDinv;
+    bgemm.s0 = bgemm.s1 = bgemm.s2 = strideA;
+    const bool lookahead = ctx->lookahead && count == 1;
     bool side_busy = false;
     // outer panel width: 512 (K = 512 trailing updates); 1024 measured 3 % faster at n = 32768 (205 -> 198.5 ms), equal at 8192
     static const int outer_env = [] { const char *e = getenv("GPCORE_OUTER"); int v = e ? atoi(e) : 0; return (v >= GP_NB && v % GP_NB == 0) ? v : 0; }();
@@ -105,19 +114,19 @@ void chol_blocked(gp_ctx *ctx, double *A, int np, int lda, double *dinv, int ext
             double *Akk = A + (size_t)k0 + (size_t)k0 * lda;
             double *dk = dinv + (size_t)k0 * 16;
             gp_prof_begin(ctx, GP_PROF_POTRF_DIAG);
-            gpk_potrf_diag128(s, Akk, lda, dk, ctx->d_info, k0);
-            gp_prof_end(ctx, GP_PROF_POTRF_DIAG, (double)GP_NB * GP_NB * GP_NB / 3.0);
+            gpk_potrf_diag128(s, Akk, lda, dk, info, k0, bdiag);
+            gp_prof_end(ctx, GP_PROF_POTRF_DIAG, (double)count * GP_NB * GP_NB * GP_NB / 3.0);
             const int r = rows - (k0 + GP_NB);
             if (r <= 0) continue;
             double *A21 = Akk + GP_NB;
             gp_prof_begin(ctx, GP_PROF_TRSM);
-            gpk_trsm_panel128(s, A21, r, lda, Akk, lda, dk, nullptr);
-            gp_prof_end(ctx, GP_PROF_TRSM, (double)r * GP_NB * GP_NB);
+            gpk_trsm_panel128(s, A21, r, lda, Akk, lda, dk, nullptr, nullptr, nullptr, btrsm);
+            gp_prof_end(ctx, GP_PROF_TRSM, (double)count * r * GP_NB * GP_NB);
             const int wc = K0 + wcols - (k0 + GP_NB);
             if (wc > 0) {
                 gp_prof_begin(ctx, GP_PROF_PANEL_UPD);
-                gpk_gemm_nt(s, r, wc, GP_NB, -1.0, A21, lda, A21, lda, 1.0, A21 + (size_t)GP_NB * lda, lda, 1);
-                gp_prof_end(ctx, GP_PROF_PANEL_UPD, trapezoid_flops(r, wc, GP_NB));
+                gpk_gemm_nt(s, r, wc, GP_NB, -1.0, A21, lda, A21, lda, 1.0, A21 + (size_t)GP_NB * lda, lda, 1, 0, bgemm);
+                gp_prof_end(ctx, GP_PROF_PANEL_UPD, count * trapezoid_flops(r, wc, GP_NB));
             }
         }
         const int c1 = K0 + wcols;
@@ -125,7 +134,7 @@ void chol_blocked(gp_ctx *ctx, double *A, int np, int lda, double *dinv, int ext
         if (R <= 0) break;
         if (side_busy) { (void)hipStreamWaitEvent(s, ctx->ev_b, 0); side_busy = false; }
         const double *P = A + (size_t)c1 + (size_t)K0 * lda;
-        const int nnext = ctx->lookahead ? std::min(OUTER, R) : R;
+        const int nnext = lookahead ? std::min(OUTER, R) : R;
         if (R > nnext) {
             (void)hipEventRecord(ctx->ev_a, s);          // outer panel K0 is complete at this point
             (void)hipStreamWaitEvent(s2, ctx->ev_a, 0);
@@ -138,8 +147,8 @@ void chol_blocked(gp_ctx *ctx, double *A, int np, int lda, double *dinv, int ext
             side_busy = true;
         }
         gp_prof_begin(ctx, GP_PROF_SYRK);
-        gpk_gemm_nt(s, rows - c1, nnext, wcols, -1.0, P, lda, P, lda, 1.0, A + (size_t)c1 + (size_t)c1 * lda, lda, 1);
-        gp_prof_end(ctx, GP_PROF_SYRK, trapezoid_flops(rows - c1, nnext, wcols));
+        gpk_gemm_nt(s, rows - c1, nnext, wcols, -1.0, P, lda, P, lda, 1.0, A + (size_t)c1 + (size_t)c1 * lda, lda, 1, 0, bgemm);
+        gp_prof_end(ctx, GP_PROF_SYRK, count * trapezoid_flops(rows - c1, nnext, wcols));
     }
     if (side_busy) (void)hipStreamWaitEvent(s, ctx->ev_b, 0);
 }
@@ -160,7 +169,9 @@ void solve_rows_lower(gp_ctx *ctx, double *Vt, int mp, const double *L, int np, 
     // Few rows (mp/128 tiles per step would leave most of the 256 CUs idle): right-looking -- after block column i is
     // solved, ALL later block columns are updated by one wide GEMM (K = 128).  Many rows (the posterior batches):
     // left-looking -- each block column is hit once by a long-K GEMM, the most efficient shape for the MFMA kernel.
-    const bool right_looking = (mp / GP_NB) < 192;
+    // GPCORE_ROWS_LEFT_MIN (row tiles) moves the switch point; the tests use it to run both forms at small sizes.
+    static const int left_min = [] { const char *e = getenv("GPCORE_ROWS_LEFT_MIN"); int v = e ? atoi(e) : 0; return v > 0 ? v : 192; }();
+    const bool right_looking = (mp / GP_NB) < left_min;
     for (int i = 0; i < nblk; ++i) {
         double *Vi = Vt + (size_t)i * GP_NB * mp;
         if (!right_looking && i > 0) {
@@ -187,22 +198,30 @@ void solve_rows_lower(gp_ctx *ctx, double *Vt, int mp, const double *L, int np, 
 //   T[0:(i+1)*128, j] -= T_i * L[j-block, i-block]^T   for all j > i    (M = (i+1)*128, N = np-(i+1)*128, K = 128).
 // Same n^3/3 flops as a structure-exploiting left-looking solve, but each step is one wide GEMM (up to n^2/4/128^2
 // tiles) instead of an (np/128)-tile one -- at n = 4096 the left-looking form keeps 32 of 256 CUs busy.
-void inverse_transpose_lower(gp_ctx *ctx, double *T, const double *L, int np, int ldl, const double *dinv) {
+// (A two-level form -- K = 128 updates kept inside a 512- or 1024-wide outer block, one long-K update to the right of it
+// per outer block -- measured 2-4 % SLOWER at n = 4096 (C3: 354 vs 360 settings/s): the long-K GEMM multiplies the zero
+// lower part of the outer block and the K = 128 updates lose their width.)
+void inverse_transpose_lower(gp_ctx *ctx, double *T, const double *L, int np, int ldl, const double *dinv, int count = 1, size_t strideT = 0,
+                             size_t strideL = 0, size_t strideDinv = 0) {
     hipStream_t s = ctx->stream;
     const int nblk = np / GP_NB;
-    gpk_set_identity(s, T, np, np);
+    gp_batch btrsm, bgemm;
+    btrsm.count = bgemm.count = count;
+    btrsm.s0 = strideT, btrsm.s1 = strideL, btrsm.s2 = strideDinv;
+    bgemm.s0 = strideT, bgemm.s1 = strideL, bgemm.s2 = strideT;
+    for (int g = 0; g < count; ++g) gpk_set_identity(s, T + g * strideT, np, np);
     for (int i = 0; i < nblk; ++i) {
         const int rows = (i + 1) * GP_NB;   // non-zero rows of block column i
         double *Ti = T + (size_t)i * GP_NB * np;
         gp_prof_begin(ctx, GP_PROF_TRSM);
-        gpk_trsm_panel128(s, Ti, rows, np, L + (size_t)i * GP_NB + (size_t)i * GP_NB * ldl, ldl, dinv + (size_t)i * GP_NB * 16, nullptr);
-        gp_prof_end(ctx, GP_PROF_TRSM, (double)rows * GP_NB * GP_NB);
+        gpk_trsm_panel128(s, Ti, rows, np, L + (size_t)i * GP_NB + (size_t)i * GP_NB * ldl, ldl, dinv + (size_t)i * GP_NB * 16, nullptr, nullptr, nullptr, btrsm);
+        gp_prof_end(ctx, GP_PROF_TRSM, (double)count * rows * GP_NB * GP_NB);
         const int rest = np - rows;
         if (rest > 0) {
             gp_prof_begin(ctx, GP_PROF_GEMM);
             gpk_gemm_nt(s, rows, rest, GP_NB, -1.0, Ti, np, L + (size_t)rows + (size_t)i * GP_NB * ldl, ldl, 1.0,
-                        T + (size_t)rows * np, np, 0);
-            gp_prof_end(ctx, GP_PROF_GEMM, 2.0 * rows * (double)rest * GP_NB);
+                        T + (size_t)rows * np, np, 0, 0, bgemm);
+            gp_prof_end(ctx, GP_PROF_GEMM, 2.0 * count * rows * (double)rest * GP_NB);
         }
     }
 }
@@ -761,65 +780,119 @@ static gp_status trsm_impl(gp_ctx *ctx, int trans, const double *L, int n, int l
 
 // ------------------------------------------------------------------------------------------------
 // LML + gradient at B hyper-parameter settings (GpPredictor.logLikelihoodWithDerivatives :60-80):
-//   fit -> (L, alpha, LML);  T = L^-T (rows of I solved against L);  Kinv = T T^T (MFMA syrk, k >= row block);
-//   fused traces over W = alpha alpha^T - Kinv.
+//   fit -> (L, t = L^-1 y, LML);  T = L^-T (rows of I solved against L);  Kinv = T T^T (MFMA syrk, k >= row block);
+//   alpha = T t;  fused traces over W = alpha alpha^T - Kinv.
 // ------------------------------------------------------------------------------------------------
 namespace {
 
-// one worker = one context (own stream + workspaces) + one resident model; evaluates settings pulled from a shared counter
+constexpr int LML_GEMV_CHUNKS = 32;
+
+// One worker = one context (own stream + workspaces) that evaluates settings G at a time IN LOCKSTEP: the G problems have
+// identical shapes, so every step of the factorisation / triangular inversion is ONE launch covering all of them
+// (blockIdx.y = problem).  The latency-bound diagonal-block chain is paid once per group instead of once per setting and
+// the K = 128 updates launch G times the tiles, which is what fills 256 CUs at n = 4096.
 struct lml_worker {
     gp_ctx *ctx = nullptr;
-    gp_model *m = nullptr;
-    double *T = nullptr, *Kinv = nullptr, *partials = nullptr, *dres = nullptr;
+    int G = 1, n = 0, d = 0, np = 0, ldl = 0;
+    double *dX = nullptr, *dy = nullptr, *L = nullptr, *T = nullptr, *Kinv = nullptr, *partials = nullptr, *gemv_part = nullptr, *small = nullptr;
+    int *info = nullptr;
+    size_t sL = 0, sT = 0, sSmall = 0, sPart = 0;
+    std::vector<double> hres;
+    std::vector<int> hinfo;
     gp_status st = GP_OK;
+    // per-problem small block: dinv (np*16) | t (np) | alpha (np) | res (P+1, padded to 72)
+    double *dinv(int g) const { return small + g * sSmall; }
+    double *tvec(int g) const { return dinv(g) + (size_t)np * 16; }
+    double *alpha(int g) const { return tvec(g) + np; }
+    double *res(int g) const { return alpha(g) + np; }
 };
+
+size_t lml_bytes_per_setting(int np, bool with_grad) {
+    return sizeof(double) * ((size_t)(np + GP_NB) * np + (with_grad ? 2 * (size_t)np * np : 0) + (size_t)np * 64);
+}
 
 gp_status lml_worker_setup(lml_worker &w, const double *X, int n, int d, int ldx, const double *y, int nparams) {
     gp_ctx *ctx = w.ctx;
     GP_HIP(ctx, hipSetDevice(ctx->device));
-    GP_TRY(model_alloc(ctx, n, d, true, &w.m));
-    GP_TRY(upload_2d(ctx, w.m->dX, n, X, ldx, n, d));
-    GP_TRY(upload_2d(ctx, w.m->dy, n, y, n, n, 1));
-    const int np = w.m->np, P = d + 2;
+    const int np = ((n + GP_NB - 1) / GP_NB) * GP_NB, G = w.G;
+    w.n = n, w.d = d, w.np = np, w.ldl = np + GP_NB;
+    w.sL = (size_t)w.ldl * np, w.sT = (size_t)np * np, w.sSmall = (size_t)np * 18 + 72;
+    w.sPart = (size_t)gpk_lml_grad_partials_size(n, d);
+    GP_TRY(ws_get(ctx, WS_A, sizeof(double) * ((size_t)n * d + np), &w.dX));
+    w.dy = w.dX + (size_t)n * d;
+    GP_TRY(ws_get(ctx, WS_B, sizeof(double) * w.sL * G, &w.L));
+    GP_TRY(ws_get(ctx, WS_C, sizeof(double) * w.sSmall * G, &w.small));
+    double *ip = nullptr;
+    GP_TRY(ws_get(ctx, WS_SUMSQ, sizeof(double) * (size_t)(G + 2), &ip));
+    w.info = reinterpret_cast<int *>(ip);
     if (nparams > 0) {
-        GP_TRY(ws_get(ctx, WS_VT, sizeof(double) * (size_t)np * np, &w.T));
-        GP_TRY(ws_get(ctx, WS_D, sizeof(double) * (size_t)np * np, &w.Kinv));
-        GP_TRY(ws_get(ctx, WS_PARTIAL, sizeof(double) * (size_t)gpk_lml_grad_partials_size(n, d), &w.partials));
+        GP_TRY(ws_get(ctx, WS_VT, sizeof(double) * w.sT * G, &w.T));
+        GP_TRY(ws_get(ctx, WS_D, sizeof(double) * w.sT * G, &w.Kinv));
+        GP_TRY(ws_get(ctx, WS_PARTIAL, sizeof(double) * w.sPart * G, &w.partials));
+        GP_TRY(ws_get(ctx, WS_E, sizeof(double) * (size_t)LML_GEMV_CHUNKS * np * G, &w.gemv_part));
     }
-    GP_TRY(ws_get(ctx, WS_C, sizeof(double) * (size_t)(P + 1), &w.dres));
+    GP_TRY(upload_2d(ctx, w.dX, n, X, ldx, n, d));
+    GP_HIP(ctx, hipMemsetAsync(w.dy, 0, sizeof(double) * np, ctx->stream));
+    GP_TRY(upload_2d(ctx, w.dy, n, y, n, n, 1));
+    GP_HIP(ctx, hipMemsetAsync(w.L, 0, sizeof(double) * w.sL * G, ctx->stream));   // upper triangles and the 127 spare rows under y^T
+    w.hres.assign((size_t)72 * G, 0.0);
+    w.hinfo.assign(G, 0);
     return GP_OK;
 }
 
-gp_status lml_worker_eval(lml_worker &w, const double *theta, int nparams, double sigma_noise, double *lml, double *grad, int *info) {
+// settings thetas[0 .. g) (g <= G) -> lml[0 .. g), grad, info
+gp_status lml_worker_eval(lml_worker &w, const double *thetas, int g, int nparams, double sigma_noise, double *lml, double *grad, int *info) {
     gp_ctx *ctx = w.ctx;
-    gp_model *m = w.m;
     hipStream_t s = ctx->stream;
-    const int np = m->np, n = m->n, d = m->d, P = d + 2;
-    GP_TRY(gp_model_refit_dev(m, theta, sigma_noise));
-    if (nparams > 0) {
-        inverse_transpose_lower(ctx, w.T, m->dL, np, m->ldl, m->ddinv);          // T = L^-T (upper triangular)
-        gp_prof_begin(ctx, GP_PROF_SYRK);
-        gpk_gemm_nt(s, np, np, np, 1.0, w.T, np, w.T, np, 0.0, w.Kinv, np, 1, 1);  // Kinv = T T^T, lower
-        gp_prof_end(ctx, GP_PROF_SYRK, (double)np * np * np / 3.0);
-        ensure_alpha(m);
-        gpk_lml_grad_traces(s, m->dX, n, d, n, theta, m->dalpha, w.Kinv, np, w.partials, w.dres + 1);
+    const int np = w.np, n = w.n, d = w.d, P = d + 2, ldl = w.ldl;
+    const double extra = std::isnan(sigma_noise) ? 0.0 : sigma_noise;
+    GP_HIP(ctx, hipMemsetAsync(w.info, 0, sizeof(int) * g, s));
+    for (int j = 0; j < g; ++j) {
+        double *Lj = w.L + j * w.sL;
+        gp_prof_begin(ctx, GP_PROF_GRAM);
+        gpk_gram_sym(s, w.dX, n, d, n, thetas + (size_t)j * P, Lj, ldl, 0, extra);
+        gp_prof_end(ctx, GP_PROF_GRAM, 8.0 * n * (n + 1.0) / 2.0 + 8.0 * n * d);
+        gpk_pad_identity(s, Lj, n, np, ldl);
+        gpk_copy_strided(s, Lj + np, (size_t)ldl, w.dy, 1, np);       // y^T rides through the factorisation in row np
     }
-    double host[66 + 1];
-    GP_HIP(ctx, hipMemcpyAsync(w.dres, m->dlml, sizeof(double), hipMemcpyDeviceToDevice, s));
-    GP_HIP(ctx, hipMemcpyAsync(host, w.dres, sizeof(double) * (P + 1), hipMemcpyDeviceToHost, s));
-    int h = 0;
-    GP_TRY(read_info(ctx, &h));   // also syncs the stream
-    if (info) *info = h;
-    *lml = h ? NAN : host[0];
-    for (int p = 0; p < nparams; ++p) grad[p] = h ? NAN : host[1 + p];
+    chol_blocked(ctx, w.L, np, ldl, w.small, GP_NB, g, w.sL, w.sSmall, w.info);
+    for (int j = 0; j < g; ++j) {
+        const double *Lj = w.L + j * w.sL;
+        gpk_copy_strided(s, w.tvec(j), 1, Lj + np, (size_t)ldl, np);   // t = L^-1 y
+        gpk_lml(s, Lj, n, ldl, w.tvec(j), w.res(j));
+    }
+    if (nparams > 0) {
+        inverse_transpose_lower(ctx, w.T, w.L, np, ldl, w.small, g, w.sT, w.sL, w.sSmall);     // T = L^-T (upper triangular)
+        gp_batch bk;
+        bk.count = g, bk.s0 = bk.s1 = bk.s2 = w.sT;
+        gp_prof_begin(ctx, GP_PROF_SYRK);
+        gpk_gemm_nt(s, np, np, np, 1.0, w.T, np, w.T, np, 0.0, w.Kinv, np, 1, 1, bk);          // Kinv = T T^T, lower
+        gp_prof_end(ctx, GP_PROF_SYRK, (double)g * np * np * np / 3.0);
+        for (int j = 0; j < g; ++j) {
+            // alpha = L^-T t = T t: one matrix-vector pass over the T already here, not np/128 substitution steps
+            gpk_gemv_rows(s, w.T + j * w.sT, np, np, np, w.tvec(j), w.alpha(j), w.gemv_part + (size_t)j * LML_GEMV_CHUNKS * np, LML_GEMV_CHUNKS);
+            gpk_lml_grad_traces(s, w.dX, n, d, n, thetas + (size_t)j * P, w.alpha(j), w.Kinv + j * w.sT, np, w.partials + j * w.sPart, w.res(j) + 1);
+        }
+    }
+    GP_HIP(ctx, hipMemcpy2DAsync(w.hres.data(), 72 * sizeof(double), w.res(0), w.sSmall * sizeof(double), (P + 1) * sizeof(double), g,
+                                 hipMemcpyDeviceToHost, s));
+    GP_HIP(ctx, hipMemcpyAsync(w.hinfo.data(), w.info, sizeof(int) * g, hipMemcpyDeviceToHost, s));
+    GP_HIP(ctx, hipStreamSynchronize(s));
+    for (int j = 0; j < g; ++j) {
+        const int h = w.hinfo[j];
+        if (info) info[j] = h;
+        lml[j] = h ? NAN : w.hres[(size_t)72 * j];
+        for (int p = 0; p < nparams; ++p) grad[(size_t)j * nparams + p] = h ? NAN : w.hres[(size_t)72 * j + 1 + p];
+    }
     return GP_OK;
 }
 
 }  // namespace
 
-// Settings are independent: a few of them are kept in flight at once, each on its own stream (own context, own host
-// thread issuing the launches), so the latency-bound diagonal-block chain of one setting overlaps the GEMMs of another.
-// GPCORE_LML_WORKERS (default 6, 1 for n > 12288) sets how many; results do not depend on it.
+// Settings are independent and identically shaped.  They are evaluated in lockstep groups of G (one launch per algorithm
+// step for the whole group); a second worker (own context, stream and host thread) runs another group concurrently so
+// that one group's single-workgroup diagonal steps overlap the other's GEMMs.  GPCORE_LML_GROUP (default 8, capped by free
+// HBM) and GPCORE_LML_WORKERS (default 2) set the shape; results do not depend on either.
 extern "C" gp_status gp_lml_grad_rbf_batched(gp_ctx *ctx, const double *X, int n, int d, int ldx, const double *y, const double *thetas,
                                              int B, int nparams, double sigma_noise, double *lml, double *grad, int *info) {
     if (!ctx) return GP_EINVAL;
@@ -828,9 +901,21 @@ extern "C" gp_status gp_lml_grad_rbf_batched(gp_ctx *ctx, const double *X, int n
     const int P = d + 2;
     GP_REQUIRE(ctx, nparams >= 0 && nparams <= P && (nparams == 0 || grad), "0 <= nparams <= d+2");
     if (B == 0) return GP_OK;
-    int nw = (n > 12288) ? 1 : 6;
+    GP_HIP(ctx, hipSetDevice(ctx->device));
+    int nw = 2, G = 8;
     if (const char *e = getenv("GPCORE_LML_WORKERS")) nw = atoi(e);
-    nw = std::max(1, std::min(std::min(nw, 8), B));
+    if (const char *e = getenv("GPCORE_LML_GROUP")) G = atoi(e);
+    G = std::max(1, std::min(G, 32));
+    nw = std::max(1, std::min(std::min(nw, 8), (B + G - 1) / G));
+    G = std::min(G, (B + nw - 1) / nw);
+    {   // keep the groups within half of the HBM that is free right now
+        size_t free_b = 0, total_b = 0;
+        GP_HIP(ctx, hipMemGetInfo(&free_b, &total_b));
+        const int np = ((n + GP_NB - 1) / GP_NB) * GP_NB;
+        const size_t per = lml_bytes_per_setting(np, nparams > 0);
+        while (G > 1 && (size_t)nw * G * per > free_b / 2) --G;
+        while (nw > 1 && (size_t)nw * G * per > free_b / 2) --nw;
+    }
     // helper contexts are cached on the caller's context
     ctx_ext *x = ext_of(ctx);
     while ((int)x->children.size() < nw - 1) {
@@ -840,18 +925,18 @@ extern "C" gp_status gp_lml_grad_rbf_batched(gp_ctx *ctx, const double *X, int n
     }
     nw = std::min(nw, (int)x->children.size() + 1);
     std::vector<lml_worker> ws(nw);
-    for (int k = 0; k < nw; ++k) ws[k].ctx = (k == 0) ? ctx : x->children[k - 1];
+    for (int k = 0; k < nw; ++k) { ws[k].ctx = (k == 0) ? ctx : x->children[k - 1]; ws[k].G = G; }
     std::atomic<int> next{0};
     auto run = [&](int k) {
         lml_worker &w = ws[k];
         w.st = lml_worker_setup(w, X, n, d, ldx, y, nparams);
         while (w.st == GP_OK) {
-            const int b = next.fetch_add(1);
+            const int b = next.fetch_add(G);
             if (b >= B) break;
-            w.st = lml_worker_eval(w, thetas + (size_t)b * P, nparams, sigma_noise, lml + b, grad ? grad + (size_t)b * nparams : nullptr,
+            const int g = std::min(G, B - b);
+            w.st = lml_worker_eval(w, thetas + (size_t)b * P, g, nparams, sigma_noise, lml + b, grad ? grad + (size_t)b * nparams : nullptr,
                                    info ? info + b : nullptr);
         }
-        if (w.m) { gp_model_destroy(w.m); w.m = nullptr; }
     };
     std::vector<std::thread> threads;
     for (int k = 1; k < nw; ++k) threads.emplace_back(run, k);

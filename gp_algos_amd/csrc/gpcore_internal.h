@@ -68,12 +68,19 @@ struct gp_model {
 void gp_prof_begin(gp_ctx *ctx, int cls, hipStream_t s = nullptr);
 void gp_prof_end(gp_ctx *ctx, int cls, double work, hipStream_t s = nullptr);
 
+// A lockstep batch: `count` problems of identical shape handled by ONE launch (blockIdx.y picks the problem); the three
+// strides (in doubles) are applied to the launcher's pointer operands in the order they appear in its signature.
+struct gp_batch {
+    int count = 1;
+    size_t s0 = 0, s1 = 0, s2 = 0;
+};
+
 // ---- kernel launchers (each asynchronous on `s`) ----
 // C[MxN] = beta*C + alpha * A[MxK] * B[NxK]^T, column-major; M,N multiples of 128, K multiple of 16.
 // lower != 0: M >= N, only tiles on/below the diagonal (bi >= bj) are computed; on diagonal tiles only i >= j is stored.
 // ktri != 0: A(i,k) is zero for k < i (upper-triangular operand): each tile starts its k loop at its row block.
 void gpk_gemm_nt(hipStream_t s, int M, int N, int K, double alpha, const double *A, int lda, const double *B, int ldb,
-                 double beta, double *C, int ldc, int lower, int ktri = 0);
+                 double beta, double *C, int ldc, int lower, int ktri = 0, gp_batch bt = gp_batch());   // strides: A, B, C
 // ARD-RBF Gram.  theta on host.  symmetric: Xb == Xa, noise on the diagonal, tiles bi >= bj only (mirrored if full).
 void gpk_gram_sym(hipStream_t s, const double *X, int n, int d, int ldx, const double *theta, double *K, int ldk, int full, double extra_diag);
 void gpk_gram_cross(hipStream_t s, const double *Xs, int m, int ldxs, const double *X, int n, int ldx, int d, const double *theta, double *Ks, int ldks);
@@ -102,10 +109,10 @@ double gpk_probe_mfma(hipStream_t s, int num_cu, int waves_per_simd, double *clo
 int gpk_init_diag_kernels();
 // MFMA-blocked critical-path kernels (kernels_diag.hip).  dinv holds the inverses of the 16x16 diagonal
 // tiles of L: tile b (rows 16b..16b+15) at dinv + 256*b, element (c,k) at c + 16k; a 128-block owns 8 tiles.
-void gpk_potrf_diag128(hipStream_t s, double *A, int lda, double *dinv_k, int *d_info, int base);
+void gpk_potrf_diag128(hipStream_t s, double *A, int lda, double *dinv_k, int *d_info, int base, gp_batch bt = gp_batch());   // strides: A, dinv; d_info + 1 per problem
 // optional fused row reductions: sumsq[p] += sum_c X(p,c)^2 ; dots[p] += sum_c X(p,c) tvec[c]
 void gpk_trsm_panel128(hipStream_t s, double *X, int M, int ldx, const double *Lkk, int ldl, const double *dinv_k, double *sumsq,
-                       const double *tvec = nullptr, double *dots = nullptr);
+                       const double *tvec = nullptr, double *dots = nullptr, gp_batch bt = gp_batch());   // strides: X, Lkk, dinv (no fused reductions when batched)
 void gpk_fwd_step(hipStream_t s, const double *L, int ldl, const double *dinv_k, double *t, double *sol, int k0, int r);
 void gpk_bwd_step(hipStream_t s, const double *L, int ldl, const double *dinv_k, double *t, double *sol, int k0);
 void gpk_tile_inverses(hipStream_t s, const double *L, int np, int ldl, double *dinv);

@@ -57,8 +57,11 @@ __device__ __forceinline__ void load_block_lds(double *a, const double *__restri
 
 // -------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void potrf_diag128_kernel(double *__restrict__ A, int lda, double *__restrict__ dinv,
-                                                            int *info, int base) {
+                                                            int *info, int base, gp_batch bt) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
+    A += (size_t)blockIdx.x * bt.s0;      // one workgroup per problem of a lockstep batch
+    dinv += (size_t)blockIdx.x * bt.s1;
+    info += blockIdx.x;
     double *a = sm;                 // NB x PLS
     double *dv = sm + NB * PLS;     // 16 x 16 inverse of the current diagonal tile, (c,k) at c + 16k
     int *flag = reinterpret_cast<int *>(dv + 256);
@@ -203,8 +206,11 @@ __device__ __forceinline__ void trsm_chunk(double *xs, int sp, int fr, int fg, c
 
 __global__ __launch_bounds__(256, 2) void trsm_panel128_kernel(double *__restrict__ X, int ldx, const double *__restrict__ L, int ldl,
                                                              const double *__restrict__ dinv, double *__restrict__ sumsq,
-                                                             const double *__restrict__ tvec, double *__restrict__ dots) {
+                                                             const double *__restrict__ tvec, double *__restrict__ dots, gp_batch bt) {
     extern __shared__ __attribute__((aligned(16))) double xs[];   // NB x XS
+    X += (size_t)blockIdx.y * bt.s0;      // blockIdx.y = problem of a lockstep batch
+    L += (size_t)blockIdx.y * bt.s1;
+    dinv += (size_t)blockIdx.y * bt.s2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
     const int row0 = blockIdx.x * 64;
@@ -374,13 +380,14 @@ int gpk_init_diag_kernels() {
     return e == hipSuccess ? 0 : 1;
 }
 
-void gpk_potrf_diag128(hipStream_t s, double *A, int lda, double *dinv, int *d_info, int base) {
-    hipLaunchKernelGGL(potrf_diag128_kernel, dim3(1), dim3(256), POTRF_LDS, s, A, lda, dinv, d_info, base);
+void gpk_potrf_diag128(hipStream_t s, double *A, int lda, double *dinv, int *d_info, int base, gp_batch bt) {
+    if (bt.count <= 0) return;
+    hipLaunchKernelGGL(potrf_diag128_kernel, dim3(bt.count), dim3(256), POTRF_LDS, s, A, lda, dinv, d_info, base, bt);
 }
 void gpk_trsm_panel128(hipStream_t s, double *X, int M, int ldx, const double *Lkk, int ldl, const double *dinv, double *sumsq,
-                       const double *tvec, double *dots) {
-    if (M <= 0) return;
-    hipLaunchKernelGGL(trsm_panel128_kernel, dim3(M / 64), dim3(256), TRSM_LDS, s, X, ldx, Lkk, ldl, dinv, sumsq, tvec, dots);
+                       const double *tvec, double *dots, gp_batch bt) {
+    if (M <= 0 || bt.count <= 0) return;
+    hipLaunchKernelGGL(trsm_panel128_kernel, dim3(M / 64, bt.count), dim3(256), TRSM_LDS, s, X, ldx, Lkk, ldl, dinv, sumsq, tvec, dots, bt);
 }
 void gpk_fwd_step(hipStream_t s, const double *L, int ldl, const double *dinv_k, double *t, double *sol, int k0, int r) {
     int grid = r > 0 ? (r + 255) / 256 : 1;

@@ -61,13 +61,28 @@ __device__ __forceinline__ void tile_coords_lower(int t, int nbm, int nbn, int &
 template <int LOWER, int HAS_BETA, int NW>
 __global__ __launch_bounds__(NW * 64, NW / 2) void gemm_nt_f64_kernel(int M, int N, int K, double alpha, const double *__restrict__ A, int lda,
                                                            const double *__restrict__ B, int ldb, double beta,
-                                                           double *__restrict__ C, int ldc, int ktri) {
+                                                           double *__restrict__ C, int ldc, int ktri, gp_batch bt) {
     __shared__ __attribute__((aligned(16))) double smem[2 * 2 * TK * LDS_STRIDE];
     double *As = smem;                          // [2][TK][LDS_STRIDE]
     double *Bs = smem + 2 * TK * LDS_STRIDE;    // [2][TK][LDS_STRIDE]
 
     int bi, bj;
-    if (LOWER) {
+    int prob = blockIdx.y;   // problem of a lockstep batch (same shapes, operands bt.s* doubles apart); a single problem has gridDim.y == 1
+    if (LOWER && ktri) {
+        // The k loop of tile row bi runs over K - bi*128, so equal tile COUNTS per XCD would leave the XCD holding the first rows
+        // with twice the average work (measured: 30 TFLOP/s).  Deal whole tile rows to the XCDs instead (XCD x owns rows
+        // x, x+8, ...): the k-work per XCD is then equal within 3 %, a row's tiles share their A row panel in that XCD's L2,
+        // and each XCD starts with its longest rows.  A batch multiplies every row's entry count (1-D grid, gridDim.y == 1).
+        const int x = blockIdx.x & 7, nb = M / TM;
+        int e = blockIdx.x >> 3;
+        bi = -1;
+        for (int r = x; r < nb; r += 8) {
+            const int cnt = (r + 1) * bt.count;
+            if (e < cnt) { bi = r; prob = e / (r + 1); bj = e - prob * (r + 1); break; }
+            e -= cnt;
+        }
+        if (bi < 0) return;   // padding workgroups of the XCDs that own fewer tiles
+    } else if (LOWER) {
         // XCD-aware: block ids are dealt round-robin over the 8 XCDs; hand each XCD a contiguous run of the order above
         const int nwg = gridDim.x, id = blockIdx.x;
         const int q = nwg >> 3, r = nwg & 7, xcd = id & 7;
@@ -84,6 +99,9 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void gemm_nt_f64_kernel(int M, int
         bi = swz % nbm;
         bj = swz / nbm;
     }
+    A += (size_t)prob * bt.s0;
+    B += (size_t)prob * bt.s1;
+    C += (size_t)prob * bt.s2;
     const int row0 = bi * TM, col0 = bj * TN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int NT = (NW == 8) ? 2 : 4;          // 16-column accumulator tiles per wave (8 waves: 64 x 32 per wave)
@@ -203,14 +221,26 @@ __global__ __launch_bounds__(256) void mfma_probe_kernel(double *out, unsigned l
 }  // namespace
 
 void gpk_gemm_nt(hipStream_t s, int M, int N, int K, double alpha, const double *A, int lda, const double *B, int ldb,
-                 double beta, double *C, int ldc, int lower, int ktri) {
-    if (M <= 0 || N <= 0) return;
+                 double beta, double *C, int ldc, int lower, int ktri, gp_batch bt) {
+    if (M <= 0 || N <= 0 || bt.count <= 0) return;
     const bool hb = beta != 0.0;
     // 8 waves per workgroup (64 x 32 per wave, 4 waves/SIMD at 2 workgroups/CU) measured equal to 4 waves (64 x 64 per wave) on
     // long-K launches (65 TFLOP/s both) and ~5 % better on the short-K Cholesky updates; GPCORE_GEMM_WAVES=4 selects the other.
     static const int nw = [] { const char *e = getenv("GPCORE_GEMM_WAVES"); return (e && atoi(e) == 4) ? 4 : 8; }();
-    const int ntiles = lower ? ((N / TN) * (M / TM) - (N / TN) * ((N / TN) - 1) / 2) : (M / TM) * (N / TN);   // lower: trapezoid, M >= N
-#define GP_LAUNCH(LO, HB, NWV) hipLaunchKernelGGL((gemm_nt_f64_kernel<LO, HB, NWV>), dim3(ntiles), dim3(NWV * 64), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, ktri)
+    int ntiles = lower ? ((N / TN) * (M / TM) - (N / TN) * ((N / TN) - 1) / 2) : (M / TM) * (N / TN);   // lower: trapezoid, M >= N
+    int gy = bt.count;
+    if (ktri) {
+        if (!lower || M != N) return;   // ktri is the square lower product T T^T only
+        int most = 0;                   // grid = 8 x (entries of the XCD that owns the most tiles)
+        for (int x = 0; x < 8; ++x) {
+            int cnt = 0;
+            for (int r = x; r < M / TM; r += 8) cnt += (r + 1) * bt.count;
+            most = cnt > most ? cnt : most;
+        }
+        ntiles = 8 * most;
+        gy = 1;
+    }
+#define GP_LAUNCH(LO, HB, NWV) hipLaunchKernelGGL((gemm_nt_f64_kernel<LO, HB, NWV>), dim3(ntiles, gy), dim3(NWV * 64), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, ktri, bt)
     if (nw == 8) {
         if (lower) { if (hb) GP_LAUNCH(1, 1, 8); else GP_LAUNCH(1, 0, 8); }
         else { if (hb) GP_LAUNCH(0, 1, 8); else GP_LAUNCH(0, 0, 8); }

@@ -441,3 +441,34 @@ def test_ill_conditioned_but_pd_problem(ctx):
     assert np.max(np.abs(mean - om)) <= 1e-5 and np.max(np.abs(var - ov)) <= 1e-6
     assert abs(mdl.lml() - orc.lml(Lo, ao, p["y"])) <= 1e-9 * abs(mdl.lml())
     mdl.close()
+
+
+_LEFT_LOOKING_CHILD = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+from gp_algos_amd import core, synth
+from oracle import gp_oracle as orc
+ctx = core.Context(0)
+p = synth.config_c2(700, 5, 900)
+model = core.RegressionModel(ctx, p["X"], p["y"], p["theta"])
+mean, var = model.predict(p["Xs"])[:2]
+L, alpha = orc.fit(p["X"], p["y"], p["theta"])
+omean, ovar, _, _ = orc.predict(p["X"], p["theta"], L, alpha, p["Xs"])
+print("DMEAN", float(np.max(np.abs(mean - omean))), "DVAR", float(np.max(np.abs(var - ovar))))
+"""
+
+
+def test_left_looking_posterior_path_at_small_size(ctx, tmp_path):
+    """The many-rows (left-looking, long-K GEMM) form of the posterior solve is what C2 runs at m >= 24576; the
+    switch point is lowered through GPCORE_ROWS_LEFT_MIN in a child process (the library reads it once) so the same
+    code is checked against the oracle at a size the oracle finishes in seconds."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "left_looking_child.py"
+    script.write_text(_LEFT_LOOKING_CHILD)
+    env = dict(os.environ, GPCORE_ROWS_LEFT_MIN="1")
+    r = subprocess.run([sys.executable, str(script), root], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    tok = r.stdout.split()
+    dmean, dvar = float(tok[tok.index("DMEAN") + 1]), float(tok[tok.index("DVAR") + 1])
+    assert dmean < 1e-9 and dvar < 1e-9, r.stdout
