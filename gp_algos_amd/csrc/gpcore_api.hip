@@ -198,30 +198,42 @@ void solve_rows_lower(gp_ctx *ctx, double *Vt, int mp, const double *L, int np, 
 //   T[0:(i+1)*128, j] -= T_i * L[j-block, i-block]^T   for all j > i    (M = (i+1)*128, N = np-(i+1)*128, K = 128).
 // Same n^3/3 flops as a structure-exploiting left-looking solve, but each step is one wide GEMM (up to n^2/4/128^2
 // tiles) instead of an (np/128)-tile one -- at n = 4096 the left-looking form keeps 32 of 256 CUs busy.
-// (A two-level form -- K = 128 updates kept inside a 512- or 1024-wide outer block, one long-K update to the right of it
-// per outer block -- measured 2-4 % SLOWER at n = 4096 (C3: 354 vs 360 settings/s): the long-K GEMM multiplies the zero
-// lower part of the outer block and the K = 128 updates lose their width.)
+// For a single problem a two-level form (K = 128 updates kept inside a 512-wide outer block, one K = 512 update to the
+// right of it per outer block) measured 2-4 % slower at n = 4096 (the long-K GEMM multiplies the zero lower part of the
+// outer block and the K = 128 updates lose their width); with a lockstep batch the launches are wide enough either way and
+// the K = 128 form is bound by re-reading and re-writing the later columns of T, so batches use the two-level form.
 void inverse_transpose_lower(gp_ctx *ctx, double *T, const double *L, int np, int ldl, const double *dinv, int count = 1, size_t strideT = 0,
                              size_t strideL = 0, size_t strideDinv = 0) {
     hipStream_t s = ctx->stream;
-    const int nblk = np / GP_NB;
     gp_batch btrsm, bgemm;
     btrsm.count = bgemm.count = count;
     btrsm.s0 = strideT, btrsm.s1 = strideL, btrsm.s2 = strideDinv;
     bgemm.s0 = strideT, bgemm.s1 = strideL, bgemm.s2 = strideT;
+    // Outer block width OB: inside an outer block column the K = 128 updates touch only that block's own columns; everything
+    // to the right of it is updated once per outer block with K = OB.  OB = 128 is the plain right-looking form.
+    static const int ob_env = [] { const char *e = getenv("GPCORE_TINV_OUTER"); int v = e ? atoi(e) : 0; return (v >= GP_NB && v % GP_NB == 0) ? v : 0; }();
+    const int OB = ob_env ? ob_env : (count >= 4 ? GP_OUTER : GP_NB);
     for (int g = 0; g < count; ++g) gpk_set_identity(s, T + g * strideT, np, np);
-    for (int i = 0; i < nblk; ++i) {
-        const int rows = (i + 1) * GP_NB;   // non-zero rows of block column i
-        double *Ti = T + (size_t)i * GP_NB * np;
-        gp_prof_begin(ctx, GP_PROF_TRSM);
-        gpk_trsm_panel128(s, Ti, rows, np, L + (size_t)i * GP_NB + (size_t)i * GP_NB * ldl, ldl, dinv + (size_t)i * GP_NB * 16, nullptr, nullptr, nullptr, btrsm);
-        gp_prof_end(ctx, GP_PROF_TRSM, (double)count * rows * GP_NB * GP_NB);
-        const int rest = np - rows;
-        if (rest > 0) {
+    for (int c0 = 0; c0 < np; c0 += OB) {
+        const int c1 = std::min(np, c0 + OB);
+        for (int k0 = c0; k0 < c1; k0 += GP_NB) {
+            const int rows = k0 + GP_NB;   // non-zero rows of this block column
+            double *Tk = T + (size_t)k0 * np;
+            gp_prof_begin(ctx, GP_PROF_TRSM);
+            gpk_trsm_panel128(s, Tk, rows, np, L + (size_t)k0 + (size_t)k0 * ldl, ldl, dinv + (size_t)(k0 / GP_NB) * GP_NB * 16, nullptr, nullptr, nullptr, btrsm);
+            gp_prof_end(ctx, GP_PROF_TRSM, (double)count * rows * GP_NB * GP_NB);
+            const int rest = c1 - rows;
+            if (rest > 0) {
+                gp_prof_begin(ctx, GP_PROF_GEMM);
+                gpk_gemm_nt(s, rows, rest, GP_NB, -1.0, Tk, np, L + (size_t)rows + (size_t)k0 * ldl, ldl, 1.0, T + (size_t)rows * np, np, 0, 0, bgemm);
+                gp_prof_end(ctx, GP_PROF_GEMM, 2.0 * count * rows * (double)rest * GP_NB);
+            }
+        }
+        const int right = np - c1;
+        if (right > 0) {   // T[0:c1, c1:] -= T[0:c1, c0:c1] * L[c1:, c0:c1]^T
             gp_prof_begin(ctx, GP_PROF_GEMM);
-            gpk_gemm_nt(s, rows, rest, GP_NB, -1.0, Ti, np, L + (size_t)rows + (size_t)i * GP_NB * ldl, ldl, 1.0,
-                        T + (size_t)rows * np, np, 0, 0, bgemm);
-            gp_prof_end(ctx, GP_PROF_GEMM, 2.0 * count * rows * (double)rest * GP_NB);
+            gpk_gemm_nt(s, c1, right, c1 - c0, -1.0, T + (size_t)c0 * np, np, L + (size_t)c1 + (size_t)c0 * ldl, ldl, 1.0, T + (size_t)c1 * np, np, 0, 0, bgemm);
+            gp_prof_end(ctx, GP_PROF_GEMM, 2.0 * count * c1 * (double)right * (c1 - c0));
         }
     }
 }
@@ -891,7 +903,7 @@ gp_status lml_worker_eval(lml_worker &w, const double *thetas, int g, int nparam
 
 // Settings are independent and identically shaped.  They are evaluated in lockstep groups of G (one launch per algorithm
 // step for the whole group); a second worker (own context, stream and host thread) runs another group concurrently so
-// that one group's single-workgroup diagonal steps overlap the other's GEMMs.  GPCORE_LML_GROUP (default 8, capped by free
+// that one group's single-workgroup diagonal steps overlap the other's GEMMs.  GPCORE_LML_GROUP (default 16, capped by free
 // HBM) and GPCORE_LML_WORKERS (default 2) set the shape; results do not depend on either.
 extern "C" gp_status gp_lml_grad_rbf_batched(gp_ctx *ctx, const double *X, int n, int d, int ldx, const double *y, const double *thetas,
                                              int B, int nparams, double sigma_noise, double *lml, double *grad, int *info) {
@@ -902,7 +914,7 @@ extern "C" gp_status gp_lml_grad_rbf_batched(gp_ctx *ctx, const double *X, int n
     GP_REQUIRE(ctx, nparams >= 0 && nparams <= P && (nparams == 0 || grad), "0 <= nparams <= d+2");
     if (B == 0) return GP_OK;
     GP_HIP(ctx, hipSetDevice(ctx->device));
-    int nw = 2, G = 8;
+    int nw = 2, G = 16;
     if (const char *e = getenv("GPCORE_LML_WORKERS")) nw = atoi(e);
     if (const char *e = getenv("GPCORE_LML_GROUP")) G = atoi(e);
     G = std::max(1, std::min(G, 32));

@@ -156,91 +156,99 @@ __device__ __forceinline__ double block_sum_256(double v, double *red) {
     return r;
 }
 
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;   // valid in lane 0
+}
+
+// Each workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... and keeps per-WAVE running sums in LDS (a wave only
+// touches its own row: no atomics, fixed order), so a tile costs two barriers (staging the column points) instead of one
+// block-wide tree reduction per output -- with 64x64 tiles those reductions were most of the kernel's time.
 __global__ __launch_bounds__(256) void lml_grad_trace_kernel(const double *__restrict__ X, int n, int d, int ldx, TraceParams prm,
                                                              const double *__restrict__ alpha, const double *__restrict__ Kinv,
-                                                             int ldk, double *__restrict__ partials) {
-    __shared__ double xcs[TR_DC][TR_T];
-    __shared__ double red[256];
-    int bi, bj;
-    tile_lower_tr(blockIdx.x, bi, bj);
+                                                             int ldk, double *__restrict__ partials, int ntiles) {
+    __shared__ double xcs[TR_DMAX][TR_T];        // all d features of the tile's 64 column points
+    __shared__ double wsum[4][TR_DMAX + 2];      // per wave: [0] = S_E, [1 + k] = S_k, [d + 1] = tr W
     const int tid = threadIdx.x, ti = tid & 63, tq = tid >> 6;
-    const int gi = bi * TR_T + ti;
-    const bool diag_tile = (bi == bj);
-    const double wgt = diag_tile ? 1.0 : 2.0;
-    double r2[16], we[16];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) r2[q] = 0.0;
-    // pass 1: squared distances
-    for (int kc = 0; kc < d; kc += TR_DC) {
+    for (int e = tid; e < 4 * (TR_DMAX + 2); e += 256) (&wsum[0][0])[e] = 0.0;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        int bi, bj;
+        tile_lower_tr(t, bi, bj);
+        const int gi = bi * TR_T + ti;
+        const double wgt = (bi == bj) ? 1.0 : 2.0;
         __syncthreads();
-        for (int e = tid; e < TR_DC * TR_T; e += 256) {
-            int kk = e >> 6, jj = e & 63, gj = bj * TR_T + jj;
-            xcs[kk][jj] = (gj < n && kc + kk < d) ? X[gj + (size_t)(kc + kk) * ldx] : 0.0;
+        for (int e = tid; e < d * TR_T; e += 256) {
+            const int kk = e >> 6, jj = e & 63, gj = bj * TR_T + jj;
+            xcs[kk][jj] = (gj < n) ? X[gj + (size_t)kk * ldx] : 0.0;
         }
-        double xi[TR_DC];
-#pragma unroll
-        for (int kk = 0; kk < TR_DC; ++kk) xi[kk] = (gi < n && kc + kk < d) ? X[gi + (size_t)(kc + kk) * ldx] : 0.0;
         __syncthreads();
+        double r2[16], we[16];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int jj = tq + 4 * q;
+        for (int q = 0; q < 16; ++q) r2[q] = 0.0;
+        // pass 1: squared distances
+        for (int kc = 0; kc < d; kc += TR_DC) {
+            double xi[TR_DC], inv[TR_DC];
 #pragma unroll
             for (int kk = 0; kk < TR_DC; ++kk) {
-                double diff = xi[kk] - xcs[kk][jj];
-                double inv = (kc + kk < d) ? prm.inv_ls2[kc + kk] : 0.0;
-                r2[q] = fma(diff * inv, diff, r2[q]);
+                const bool ok = kc + kk < d;
+                xi[kk] = (gi < n && ok) ? X[gi + (size_t)(kc + kk) * ldx] : 0.0;
+                inv[kk] = ok ? prm.inv_ls2[kc + kk] : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int jj = tq + 4 * q;
+#pragma unroll
+                for (int kk = 0; kk < TR_DC; ++kk) {
+                    const double diff = xi[kk] - ((kc + kk < d) ? xcs[kc + kk][jj] : 0.0);
+                    r2[q] = fma(diff * inv[kk], diff, r2[q]);
+                }
+            }
+        }
+        // weights W_ij * E_ij (zero outside the matrix); trace of W from the diagonal tiles
+        const double ai = (gi < n) ? alpha[gi] : 0.0;
+        double sE = 0.0, tr = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int jj = tq + 4 * q, gj = bj * TR_T + jj;
+            double w = 0.0;
+            if (gi < n && gj < n) {
+                const int hi = gi > gj ? gi : gj, lo = gi > gj ? gj : gi;
+                w = ai * alpha[gj] - (Kinv ? Kinv[hi + (size_t)lo * ldk] : 0.0);
+                if (gi == gj) tr += w;
+            }
+            we[q] = wgt * w * exp(-0.5 * r2[q]);
+            sE += we[q];
+        }
+        sE = wave_sum(sE);
+        tr = wave_sum(tr);
+        if (ti == 0) { wsum[tq][0] += sE; wsum[tq][d + 1] += tr; }
+        // pass 2: per-feature weighted squared differences
+        for (int kc = 0; kc < d; kc += TR_DC) {
+            double xi[TR_DC], sk[TR_DC];
+#pragma unroll
+            for (int kk = 0; kk < TR_DC; ++kk) {
+                xi[kk] = (gi < n && kc + kk < d) ? X[gi + (size_t)(kc + kk) * ldx] : 0.0;
+                sk[kk] = 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int jj = tq + 4 * q;
+#pragma unroll
+                for (int kk = 0; kk < TR_DC; ++kk) {
+                    const double diff = xi[kk] - ((kc + kk < d) ? xcs[kc + kk][jj] : 0.0);
+                    sk[kk] = fma(we[q], diff * diff, sk[kk]);
+                }
+            }
+#pragma unroll
+            for (int kk = 0; kk < TR_DC; ++kk) {
+                const double tot = wave_sum(sk[kk]);
+                if (ti == 0 && kc + kk < d) wsum[tq][1 + kc + kk] += tot;
             }
         }
     }
-    // weights W_ij * E_ij (zero outside the matrix); trace of W from the diagonal tiles
-    const double ai = (gi < n) ? alpha[gi] : 0.0;
-    double sE = 0.0, tr = 0.0;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int jj = tq + 4 * q, gj = bj * TR_T + jj;
-        double w = 0.0;
-        if (gi < n && gj < n) {
-            const int hi = gi > gj ? gi : gj, lo = gi > gj ? gj : gi;
-            w = ai * alpha[gj] - (Kinv ? Kinv[hi + (size_t)lo * ldk] : 0.0);
-            if (gi == gj) tr += w;
-        }
-        we[q] = wgt * w * exp(-0.5 * r2[q]);
-        sE += we[q];
-    }
-    double *out = partials + (size_t)blockIdx.x * (d + 2);
-    double v = block_sum_256(sE, red);
-    if (tid == 0) out[0] = v;
-    v = block_sum_256(tr, red);
-    if (tid == 0) out[d + 1] = v;
-    // pass 2: per-feature weighted squared differences
-    for (int kc = 0; kc < d; kc += TR_DC) {
-        __syncthreads();
-        for (int e = tid; e < TR_DC * TR_T; e += 256) {
-            int kk = e >> 6, jj = e & 63, gj = bj * TR_T + jj;
-            xcs[kk][jj] = (gj < n && kc + kk < d) ? X[gj + (size_t)(kc + kk) * ldx] : 0.0;
-        }
-        double xi[TR_DC], sk[TR_DC];
-#pragma unroll
-        for (int kk = 0; kk < TR_DC; ++kk) {
-            xi[kk] = (gi < n && kc + kk < d) ? X[gi + (size_t)(kc + kk) * ldx] : 0.0;
-            sk[kk] = 0.0;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int jj = tq + 4 * q;
-#pragma unroll
-            for (int kk = 0; kk < TR_DC; ++kk) {
-                double diff = xi[kk] - xcs[kk][jj];
-                sk[kk] = fma(we[q], diff * diff, sk[kk]);
-            }
-        }
-#pragma unroll
-        for (int kk = 0; kk < TR_DC; ++kk) {
-            double tot = block_sum_256(sk[kk], red);
-            if (tid == 0 && kc + kk < d) out[1 + kc + kk] = tot;
-        }
-    }
+    __syncthreads();
+    if (tid < d + 2) partials[(size_t)blockIdx.x * (d + 2) + tid] = ((wsum[0][tid] + wsum[1][tid]) + wsum[2][tid]) + wsum[3][tid];
 }
 
 struct TraceScale { double s[TR_DMAX + 2]; };
@@ -267,9 +275,10 @@ void gpk_transpose(hipStream_t s, double *dst, int ldd, const double *src, int l
 void gpk_set_identity(hipStream_t s, double *A, int n, int lda) {
     hipLaunchKernelGGL(set_identity_kernel, dim3(1024), dim3(256), 0, s, A, n, lda);
 }
+constexpr int TR_MAX_WG = 1024;   // 4 per CU: enough to hide the Kinv stream, few enough that the fixed-order reduce stays short
 int gpk_lml_grad_partials_size(int n, int d) {
-    int nb = (n + TR_T - 1) / TR_T;
-    return nb * (nb + 1) / 2 * (d + 2);
+    (void)n;
+    return TR_MAX_WG * (d + 2);
 }
 void gpk_lml_grad_traces(hipStream_t s, const double *X, int n, int d, int ldx, const double *theta, const double *alpha,
                          const double *Kinv, int ldk, double *partials, double *out) {
@@ -285,8 +294,8 @@ void gpk_lml_grad_traces(hipStream_t s, const double *X, int n, int d, int ldx, 
         sc.s[1 + k] = 0.5 * sf * sf / (l * l * l);
     }
     sc.s[d + 1] = sn;
-    int nb = (n + TR_T - 1) / TR_T, nblocks = nb * (nb + 1) / 2;
-    hipLaunchKernelGGL(lml_grad_trace_kernel, dim3(nblocks), dim3(256), 0, s, X, n, d, ldx, prm, alpha, Kinv, ldk, partials);
+    const int nb = (n + TR_T - 1) / TR_T, ntiles = nb * (nb + 1) / 2, nblocks = ntiles < TR_MAX_WG ? ntiles : TR_MAX_WG;
+    hipLaunchKernelGGL(lml_grad_trace_kernel, dim3(nblocks), dim3(256), 0, s, X, n, d, ldx, prm, alpha, Kinv, ldk, partials, ntiles);
     hipLaunchKernelGGL(lml_grad_reduce_kernel, dim3(d + 2), dim3(256), 0, s, partials, nblocks, d + 2, sc, out);
 }
 
