@@ -162,16 +162,51 @@ void back_solve_vec(gp_ctx *ctx, const double *L, int np, int ldl, const double 
 
 // Vt (mp x np, ld mp) <- Vt * L^-T, block column by block column (forwardSolve(L, K*^T) transposed).
 // sumsq (length mp) accumulates row sums of squares of the result when non-null.
+// Row count (in 128-row tiles) from which the left-looking form is used
+int rows_left_min() {
+    static const int v = [] { const char *e = getenv("GPCORE_ROWS_LEFT_MIN"); int x = e ? atoi(e) : 0; return x > 0 ? x : 192; }();
+    return v;
+}
+
+// Lw (np x np, lower, ld np): block row i = L_ii^-1 [ -L_i,<i | I ].  With it the left-looking step for block column i,
+//   Vt_i <- (Vt_i - Vt_<i L_i,<i^T) L_ii^-T,  is ONE product  Vt_i <- Vt[:, 0:(i+1)*128] Lw[i-block, 0:(i+1)*128]^T
+// (the panel solve becomes 128 more k-steps of the GEMM that is running anyway, and its row reductions move into the GEMM
+// epilogue).  Built from L by: negated block transpose into upper form -> one batched row-panel solve (block column i
+// against L_ii, all np/128 of them in one launch) -> transpose back.  `scratch` is np x np.
+void build_lw(gp_ctx *ctx, double *Lw, double *scratch, const double *L, int np, int ldl, const double *dinv) {
+    hipStream_t s = ctx->stream;
+    gpk_lw_transpose(s, scratch, np, L, ldl, np, 1);
+    gp_batch bt;
+    bt.count = np / GP_NB;
+    bt.s0 = (size_t)GP_NB * np;             // next block column of the upper form
+    bt.s1 = (size_t)GP_NB * (ldl + 1);      // next diagonal block of L
+    bt.s2 = (size_t)GP_NB * 16;
+    bt.tri = 1;
+    gp_prof_begin(ctx, GP_PROF_TRSM);
+    gpk_trsm_panel128(s, scratch, np, np, L, ldl, dinv, nullptr, nullptr, nullptr, bt);
+    gp_prof_end(ctx, GP_PROF_TRSM, (double)np * np / 2.0 * GP_NB);
+    gpk_lw_transpose(s, Lw, np, scratch, np, np, 0);
+}
+
 void solve_rows_lower(gp_ctx *ctx, double *Vt, int mp, const double *L, int np, int ldl, const double *dinv, double *sumsq,
-                      const double *tvec = nullptr, double *dots = nullptr) {
+                      const double *tvec = nullptr, double *dots = nullptr, const double *Lw = nullptr) {
     hipStream_t s = ctx->stream;
     const int nblk = np / GP_NB;
+    if (Lw && sumsq && (mp / GP_NB) >= rows_left_min()) {
+        for (int i = 0; i < nblk; ++i) {
+            const int K = (i + 1) * GP_NB;
+            gp_prof_begin(ctx, GP_PROF_GEMM);
+            gpk_gemm_nt_rowred(s, mp, GP_NB, K, Vt, mp, Lw + (size_t)i * GP_NB, np, Vt + (size_t)i * GP_NB * mp, mp, sumsq,
+                               tvec ? tvec + (size_t)i * GP_NB : nullptr, dots);
+            gp_prof_end(ctx, GP_PROF_GEMM, 2.0 * mp * GP_NB * (double)K);
+        }
+        return;
+    }
     // Few rows (mp/128 tiles per step would leave most of the 256 CUs idle): right-looking -- after block column i is
     // solved, ALL later block columns are updated by one wide GEMM (K = 128).  Many rows (the posterior batches):
     // left-looking -- each block column is hit once by a long-K GEMM, the most efficient shape for the MFMA kernel.
     // GPCORE_ROWS_LEFT_MIN (row tiles) moves the switch point; the tests use it to run both forms at small sizes.
-    static const int left_min = [] { const char *e = getenv("GPCORE_ROWS_LEFT_MIN"); int v = e ? atoi(e) : 0; return v > 0 ? v : 192; }();
-    const bool right_looking = (mp / GP_NB) < left_min;
+    const bool right_looking = (mp / GP_NB) < rows_left_min();
     for (int i = 0; i < nblk; ++i) {
         double *Vi = Vt + (size_t)i * GP_NB * mp;
         if (!right_looking && i > 0) {
@@ -290,6 +325,7 @@ void model_factor(gp_model *m) {
     chol_blocked(ctx, m->dL, m->np, m->ldl, m->ddinv, GP_NB);
     gpk_copy_strided(s, m->dtmp, 1, m->dL + m->np, (size_t)m->ldl, m->np);     // t = L^-1 y
     m->alpha_valid = false;
+    m->lw_valid = false;
     gpk_lml(s, m->dL, m->n, m->ldl, m->dtmp, m->dlml);
 }
 
@@ -667,6 +703,7 @@ void gp_model_destroy(gp_model *m) {
     if (m->ddinv) (void)hipFree(m->ddinv);
     if (m->dtmp) (void)hipFree(m->dtmp);
     if (m->dlml) (void)hipFree(m->dlml);
+    if (m->dLw) (void)hipFree(m->dLw);
     delete m;
 }
 
@@ -691,7 +728,22 @@ static gp_status predict_core(gp_model *mdl, const double *dXs, int m, int ldxs,
     double *dots = partial;
     GP_HIP(ctx, hipMemsetAsync(sumsq, 0, sizeof(double) * mp, s));
     GP_HIP(ctx, hipMemsetAsync(dots, 0, sizeof(double) * mp, s));
-    solve_rows_lower(ctx, Vt, mp, mdl->dL, np, mdl->ldl, mdl->ddinv, sumsq, mdl->dtmp, dots);
+    const double *Lw = nullptr;
+    static const bool use_lw = [] { const char *e = getenv("GPCORE_POSTERIOR_LW"); return !e || atoi(e) != 0; }();
+    if (use_lw && mp / GP_NB >= rows_left_min()) {   // large batch: fold the panel solves into the GEMMs (see build_lw)
+        if (!mdl->dLw) {
+            hipError_t e = hipMalloc(&mdl->dLw, sizeof(double) * (size_t)np * np);
+            if (e != hipSuccess) { mdl->dLw = nullptr; GP_SET_ERR(ctx, "hipMalloc(Lw, n=%d) failed: %s", n, hipGetErrorString(e)); return GP_ENOMEM; }
+        }
+        if (!mdl->lw_valid) {
+            double *scratch;
+            GP_TRY(ws_get(ctx, WS_D, sizeof(double) * (size_t)np * np, &scratch));
+            build_lw(ctx, mdl->dLw, scratch, mdl->dL, np, mdl->ldl, mdl->ddinv);
+            mdl->lw_valid = true;
+        }
+        Lw = mdl->dLw;
+    }
+    solve_rows_lower(ctx, Vt, mp, mdl->dL, np, mdl->ldl, mdl->ddinv, sumsq, mdl->dtmp, dots, Lw);
     GP_HIP(ctx, hipMemcpyAsync(dmean, dots, sizeof(double) * m, hipMemcpyDeviceToDevice, s));
     if (dvar) {
         const double sf = mdl->theta[0], sn = mdl->theta[mdl->d + 1];

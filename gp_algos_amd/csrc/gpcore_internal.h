@@ -53,6 +53,8 @@ struct gp_model {
     double *dtmp = nullptr;          // 2 x np: t = L^-1 y (kept), scratch for the backward solve
     bool alpha_valid = false;        // alpha = L^-T t is computed lazily (predict and the LML only need t)
     double *dlml = nullptr;          // 1 double on device
+    double *dLw = nullptr;           // np x np, lower: block row i = L_ii^-1 [ -L_i,<i | I ], built on demand for large posterior batches
+    bool lw_valid = false;
     std::vector<double> theta;       // d + 2
     double sigma_noise = NAN;
     int last_info = 0;
@@ -73,6 +75,7 @@ void gp_prof_end(gp_ctx *ctx, int cls, double work, hipStream_t s = nullptr);
 struct gp_batch {
     int count = 1;
     size_t s0 = 0, s1 = 0, s2 = 0;
+    int tri = 0;   // trsm_panel128 only: problem g touches rows [0, (g+1)*128) -- the block columns of an upper-triangular matrix
 };
 
 // ---- kernel launchers (each asynchronous on `s`) ----
@@ -81,6 +84,10 @@ struct gp_batch {
 // ktri != 0: A(i,k) is zero for k < i (upper-triangular operand): each tile starts its k loop at its row block.
 void gpk_gemm_nt(hipStream_t s, int M, int N, int K, double alpha, const double *A, int lda, const double *B, int ldb,
                  double beta, double *C, int ldc, int lower, int ktri = 0, gp_batch bt = gp_batch());   // strides: A, B, C
+// C[M x 128] = A[M x K] * B[128 x K]^T with fused row reductions (sumsq[m] += sum_n C(m,n)^2, dots[m] += sum_n C(m,n) tvec[n]);
+// C may be the last 128 columns of A (in-place posterior step).
+void gpk_gemm_nt_rowred(hipStream_t s, int M, int N, int K, const double *A, int lda, const double *B, int ldb, double *C, int ldc,
+                        double *sumsq, const double *tvec, double *dots);
 // ARD-RBF Gram.  theta on host.  symmetric: Xb == Xa, noise on the diagonal, tiles bi >= bj only (mirrored if full).
 void gpk_gram_sym(hipStream_t s, const double *X, int n, int d, int ldx, const double *theta, double *K, int ldk, int full, double extra_diag);
 void gpk_gram_cross(hipStream_t s, const double *Xs, int m, int ldxs, const double *X, int n, int ldx, int d, const double *theta, double *Ks, int ldks);
@@ -91,6 +98,9 @@ void gpk_fill(hipStream_t s, double *p, size_t count, double v);
 // X (M x 128) <- X * Ukk^{-T} with Ukk UPPER triangular (back substitution per row)
 void gpk_trsm_panel_upper(hipStream_t s, double *X, int M, int ldx, const double *Ukk, int ldu);
 void gpk_transpose(hipStream_t s, double *dst, int ldd, const double *src, int lds, int rows, int cols);
+// stage = 1: dst (upper form) <- -(strict block-lower part of src)^T with identity 128-blocks on the diagonal;
+// stage = 0: dst (lower form) <- (upper form src)^T, block-lower part and diagonal blocks only.
+void gpk_lw_transpose(hipStream_t s, double *dst, int ldd, const double *src, int lds, int np, int stage);
 void gpk_set_identity(hipStream_t s, double *A, int n, int lda);
 // LML-gradient traces (GpPredictor.scala:70-78 fused): out[0..d+1] = g_p for W = alpha alpha^T - Kinv (lower triangle of Kinv read)
 void gpk_lml_grad_traces(hipStream_t s, const double *X, int n, int d, int ldx, const double *theta, const double *alpha,

@@ -118,6 +118,36 @@ __global__ __launch_bounds__(256) void transpose_kernel(double *__restrict__ dst
     }
 }
 
+// out(ro + a, co + b) = sign * in(ri + b, ci + a) for a 64x64 tile, both sides coalesced through LDS
+__device__ __forceinline__ void tile_transpose_64(double (*t)[65], double *__restrict__ out, int ldo, int ro, int co,
+                                                  const double *__restrict__ in, int ldi, int ri, int ci, double sign) {
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    __syncthreads();
+    for (int q = ty; q < 64; q += 4) t[q][tx] = in[(ri + tx) + (size_t)(ci + q) * ldi];
+    __syncthreads();
+    for (int q = ty; q < 64; q += 4) out[(ro + tx) + (size_t)(co + q) * ldo] = sign * t[tx][q];
+}
+__device__ __forceinline__ void tile_fill_64(double *__restrict__ out, int ldo, int ro, int co, bool identity) {
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int q = ty; q < 64; q += 4) out[(ro + tx) + (size_t)(co + q) * ldo] = (identity && tx == q) ? 1.0 : 0.0;
+}
+
+// The two transposes around the batched block-row scaling that builds Lw (see gpk_lw_transpose in gpcore_internal.h).
+__global__ __launch_bounds__(256) void lw_transpose_kernel(double *__restrict__ dst, int ldd, const double *__restrict__ src, int lds, int stage) {
+    __shared__ double t[64][65];
+    const int ti = blockIdx.x, tj = blockIdx.y;
+    if (tj > ti) return;
+    const bool same128 = (ti >> 1) == (tj >> 1);
+    if (stage) {
+        if (!same128) tile_transpose_64(t, dst, ldd, tj * 64, ti * 64, src, lds, ti * 64, tj * 64, -1.0);
+        else if (ti == tj) tile_fill_64(dst, ldd, ti * 64, ti * 64, true);
+        else { tile_fill_64(dst, ldd, tj * 64, ti * 64, false); tile_fill_64(dst, ldd, ti * 64, tj * 64, false); }
+    } else {
+        tile_transpose_64(t, dst, ldd, ti * 64, tj * 64, src, lds, tj * 64, ti * 64, 1.0);
+        if (same128 && ti != tj) tile_transpose_64(t, dst, ldd, tj * 64, ti * 64, src, lds, ti * 64, tj * 64, 1.0);
+    }
+}
+
 __global__ void set_identity_kernel(double *A, int n, int lda) {
     size_t total = (size_t)n * n;
     for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
@@ -271,6 +301,9 @@ void gpk_trsm_panel_upper(hipStream_t s, double *X, int M, int ldx, const double
 void gpk_transpose(hipStream_t s, double *dst, int ldd, const double *src, int lds, int rows, int cols) {
     if (rows <= 0 || cols <= 0) return;
     hipLaunchKernelGGL(transpose_kernel, dim3((rows + 63) / 64, (cols + 63) / 64), dim3(256), 0, s, dst, ldd, src, lds, rows, cols);
+}
+void gpk_lw_transpose(hipStream_t s, double *dst, int ldd, const double *src, int lds, int np, int stage) {
+    hipLaunchKernelGGL(lw_transpose_kernel, dim3(np / 64, np / 64), dim3(256), 0, s, dst, ldd, src, lds, stage);
 }
 void gpk_set_identity(hipStream_t s, double *A, int n, int lda) {
     hipLaunchKernelGGL(set_identity_kernel, dim3(1024), dim3(256), 0, s, A, n, lda);

@@ -208,6 +208,7 @@ __global__ __launch_bounds__(256, 2) void trsm_panel128_kernel(double *__restric
                                                              const double *__restrict__ dinv, double *__restrict__ sumsq,
                                                              const double *__restrict__ tvec, double *__restrict__ dots, gp_batch bt) {
     extern __shared__ __attribute__((aligned(16))) double xs[];   // NB x XS
+    if (bt.tri && (int)blockIdx.x * 64 >= ((int)blockIdx.y + 1) * NB) return;   // problem g only has (g+1)*128 non-zero rows
     X += (size_t)blockIdx.y * bt.s0;      // blockIdx.y = problem of a lockstep batch
     L += (size_t)blockIdx.y * bt.s1;
     dinv += (size_t)blockIdx.y * bt.s2;

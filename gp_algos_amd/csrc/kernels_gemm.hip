@@ -58,10 +58,18 @@ __device__ __forceinline__ void tile_coords_lower(int t, int nbm, int nbn, int &
     bi = bj = 0;   // not reached for a valid launch
 }
 
-template <int LOWER, int HAS_BETA, int NW>
+// Row reductions fused into the epilogue (posterior step: C is one 128-column block of V^T, the variance needs the row sums
+// of squares and the mean needs the row dot products with t = L^-1 y):  sumsq[m] += sum_n C(m,n)^2,  dots[m] += sum_n C(m,n) tvec[n].
+struct gemm_rowred {
+    double *sumsq = nullptr;
+    const double *tvec = nullptr;   // N values (this block column's slice of t); may be null together with dots
+    double *dots = nullptr;
+};
+
+template <int LOWER, int HAS_BETA, int NW, int RR = 0>
 __global__ __launch_bounds__(NW * 64, NW / 2) void gemm_nt_f64_kernel(int M, int N, int K, double alpha, const double *__restrict__ A, int lda,
                                                            const double *__restrict__ B, int ldb, double beta,
-                                                           double *__restrict__ C, int ldc, int ktri, gp_batch bt) {
+                                                           double *__restrict__ C, int ldc, int ktri, gp_batch bt, gemm_rowred rr) {
     __shared__ __attribute__((aligned(16))) double smem[2 * 2 * TK * LDS_STRIDE];
     double *As = smem;                          // [2][TK][LDS_STRIDE]
     double *Bs = smem + 2 * TK * LDS_STRIDE;    // [2][TK][LDS_STRIDE]
@@ -161,6 +169,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void gemm_nt_f64_kernel(int M, int
     // C is read in batches of 16 independent loads per 16-column group, then written: a load/wait/store chain per
     // element (what a naive `v += beta * *cp` compiles to) serialises 64 memory round trips per tile.
     const bool diag_tile = LOWER && (bi == bj);
+    double rsq[4] = {0.0, 0.0, 0.0, 0.0}, rdt[4] = {0.0, 0.0, 0.0, 0.0};   // RR: per (mt) row partial sums of this lane
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         double cv[4][4];
@@ -184,7 +193,35 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void gemm_nt_f64_kernel(int M, int
                 double v = alpha * acc[nt][mt][r];
                 if (HAS_BETA) v = fma(beta, cv[r][mt], v);
                 if (!(diag_tile && m < n)) C[m + (size_t)n * ldc] = v;
+                if (RR) {
+                    rsq[mt] = fma(v, v, rsq[mt]);
+                    if (rr.dots) rdt[mt] = fma(v, rr.tvec[n], rdt[mt]);
+                }
             }
+        }
+    }
+    if (RR) {
+        // lane (fr, fk) holds rows wm + mt*16 + fr over its columns; fold the 4 fk groups, then the NW/2 waves that share wm,
+        // in a fixed order, and let one thread per row add into the global accumulators (this tile owns its rows in this launch)
+        double *red = smem;   // [2][NW/2][TM]: the staging buffers are free after the k loop's last barrier
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            rsq[mt] += __shfl_xor(rsq[mt], 16, 64);
+            rsq[mt] += __shfl_xor(rsq[mt], 32, 64);
+            rdt[mt] += __shfl_xor(rdt[mt], 16, 64);
+            rdt[mt] += __shfl_xor(rdt[mt], 32, 64);
+            if (fk == 0) {
+                red[(wave >> 1) * TM + wm + mt * 16 + fr] = rsq[mt];
+                red[(NW / 2 + (wave >> 1)) * TM + wm + mt * 16 + fr] = rdt[mt];
+            }
+        }
+        __syncthreads();
+        if (tid < TM) {
+            double a = 0.0, b = 0.0;
+#pragma unroll
+            for (int g = 0; g < NW / 2; ++g) { a += red[g * TM + tid]; b += red[(NW / 2 + g) * TM + tid]; }
+            rr.sumsq[row0 + tid] += a;
+            if (rr.dots) rr.dots[row0 + tid] += b;
         }
     }
 }
@@ -223,6 +260,7 @@ __global__ __launch_bounds__(256) void mfma_probe_kernel(double *out, unsigned l
 void gpk_gemm_nt(hipStream_t s, int M, int N, int K, double alpha, const double *A, int lda, const double *B, int ldb,
                  double beta, double *C, int ldc, int lower, int ktri, gp_batch bt) {
     if (M <= 0 || N <= 0 || bt.count <= 0) return;
+    const gemm_rowred rr;
     const bool hb = beta != 0.0;
     // 8 waves per workgroup (64 x 32 per wave, 4 waves/SIMD at 2 workgroups/CU) measured equal to 4 waves (64 x 64 per wave) on
     // long-K launches (65 TFLOP/s both) and ~5 % better on the short-K Cholesky updates; GPCORE_GEMM_WAVES=4 selects the other.
@@ -240,7 +278,7 @@ void gpk_gemm_nt(hipStream_t s, int M, int N, int K, double alpha, const double 
         ntiles = 8 * most;
         gy = 1;
     }
-#define GP_LAUNCH(LO, HB, NWV) hipLaunchKernelGGL((gemm_nt_f64_kernel<LO, HB, NWV>), dim3(ntiles, gy), dim3(NWV * 64), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, ktri, bt)
+#define GP_LAUNCH(LO, HB, NWV) hipLaunchKernelGGL((gemm_nt_f64_kernel<LO, HB, NWV>), dim3(ntiles, gy), dim3(NWV * 64), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, ktri, bt, rr)
     if (nw == 8) {
         if (lower) { if (hb) GP_LAUNCH(1, 1, 8); else GP_LAUNCH(1, 0, 8); }
         else { if (hb) GP_LAUNCH(0, 1, 8); else GP_LAUNCH(0, 0, 8); }
@@ -249,6 +287,21 @@ void gpk_gemm_nt(hipStream_t s, int M, int N, int K, double alpha, const double 
         else { if (hb) GP_LAUNCH(0, 1, 4); else GP_LAUNCH(0, 0, 4); }
     }
 #undef GP_LAUNCH
+}
+
+// C = A B^T (no beta) with the row reductions above; C may alias the last N columns of A (each tile reads only its own
+// rows of A and stores after its k loop) -- the in-place posterior step.
+void gpk_gemm_nt_rowred(hipStream_t s, int M, int N, int K, const double *A, int lda, const double *B, int ldb, double *C, int ldc,
+                        double *sumsq, const double *tvec, double *dots) {
+    if (M <= 0 || N != TN) return;   // one column tile: a tile is the only writer of its rows' accumulators
+    static const int nw = [] { const char *e = getenv("GPCORE_GEMM_WAVES"); return (e && atoi(e) == 4) ? 4 : 8; }();
+    gemm_rowred rr;
+    rr.sumsq = sumsq, rr.tvec = tvec, rr.dots = dots;
+    const int ntiles = (M / TM) * (N / TN);
+    if (nw == 8)
+        hipLaunchKernelGGL((gemm_nt_f64_kernel<0, 0, 8, 1>), dim3(ntiles), dim3(512), 0, s, M, N, K, 1.0, A, lda, B, ldb, 0.0, C, ldc, 0, gp_batch(), rr);
+    else
+        hipLaunchKernelGGL((gemm_nt_f64_kernel<0, 0, 4, 1>), dim3(ntiles), dim3(256), 0, s, M, N, K, 1.0, A, lda, B, ldb, 0.0, C, ldc, 0, gp_batch(), rr);
 }
 
 double gpk_probe_mfma(hipStream_t s, int num_cu, int waves_per_simd, double *clock_mhz, double *cycles_per_mfma) {

@@ -458,15 +458,17 @@ print("DMEAN", float(np.max(np.abs(mean - omean))), "DVAR", float(np.max(np.abs(
 """
 
 
-def test_left_looking_posterior_path_at_small_size(ctx, tmp_path):
+@pytest.mark.parametrize("fold_panel_solves", ["1", "0"])
+def test_left_looking_posterior_path_at_small_size(ctx, tmp_path, fold_panel_solves):
     """The many-rows (left-looking, long-K GEMM) form of the posterior solve is what C2 runs at m >= 24576; the
     switch point is lowered through GPCORE_ROWS_LEFT_MIN in a child process (the library reads it once) so the same
-    code is checked against the oracle at a size the oracle finishes in seconds."""
+    code is checked against the oracle at a size the oracle finishes in seconds.  Both variants: panel solves folded
+    into the GEMM through Lw (default) and GEMM + row-panel solve per block column (GPCORE_POSTERIOR_LW=0)."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "left_looking_child.py"
     script.write_text(_LEFT_LOOKING_CHILD)
-    env = dict(os.environ, GPCORE_ROWS_LEFT_MIN="1")
+    env = dict(os.environ, GPCORE_ROWS_LEFT_MIN="1", GPCORE_POSTERIOR_LW=fold_panel_solves)
     r = subprocess.run([sys.executable, str(script), root], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     tok = r.stdout.split()
