@@ -67,6 +67,9 @@ __global__ __launch_bounds__(192) void ep_block_kernel(int n, int np, int i0, in
     double *cs = sm + GP_NB * LS;    // c
     double *mb = cs + GP_NB;         // mu restricted to the block
     double *sc = mb + GP_NB;         // scalars: [0] coef of the current site
+    double *tb = sc + 8;             // the block's site parameters and labels, staged once: a global load per site would put
+    double *nb = tb + GP_NB;         //   an L2 round trip on the serial chain of every one of the 128 site updates
+    double *yb = nb + GP_NB;
     const int tid = threadIdx.x, r = tid;          // waves 0,1: one block row per thread; wave 2: the site arithmetic
     const bool rowthread = tid < GP_NB;
     if (rowthread) {
@@ -80,6 +83,10 @@ __global__ __launch_bounds__(192) void ep_block_kernel(int n, int np, int i0, in
         }
         mb[r] = (i0 + r < n) ? mu[i0 + r] : 0.0;
         cs[r] = 0.0;
+        const bool live = r < bsz;
+        tb[r] = live ? tau[i0 + r] : 0.0;
+        nb[r] = live ? nu[i0 + r] : 0.0;
+        yb[r] = live ? (double)y[i0 + r] : 0.0;
     }
     __syncthreads();
     // Software pipeline over the sites of the block.  At the top of iteration t column t already holds s_t and mb is
@@ -95,13 +102,13 @@ __global__ __launch_bounds__(192) void ep_block_kernel(int n, int np, int i0, in
                 // re-associated; fp64 throughout.
                 const int i = i0 + t;
                 const double sii = Sb[t + t * LS], mui = mb[t];
-                const double to = tau[i], no = nu[i];
+                const double to = tb[t], no = nb[t];
                 const double rs = 1.0 / sii;
                 const double tc = rs - to;                              // cavity tau  :45
                 const double nc = mui * rs - no;                        // cavity nu   :46
                 const double cvr = 1.0 / tc;                            // cavity variance 1/tau
                 const double cm = nc * cvr;                             // cavity mean
-                const double yi = (double)y[i];
+                const double yi = yb[t];
                 const double rt = rsqrt(1.0 + cvr);                     // 1/sqrt(1 + sigma^2)
                 const double z = (yi * cm) * rt;
                 const double ratio = dnorm_d(z) / pnorm_d(z);           // phi(z)/Phi(z)
@@ -123,6 +130,27 @@ __global__ __launch_bounds__(192) void ep_block_kernel(int n, int np, int i0, in
         } else if (t + 1 < bsz) {
             double p0 = A[r + (t + 1) * LS], p1 = 0.0, p2 = 0.0, p3 = 0.0;
             int q = 0;
+            for (; q + 8 <= t; q += 8) {
+                // all 24 LDS reads of the group first, then the arithmetic: left alone the scheduler sometimes interleaves
+                // read / wait / fma one pair at a time, which doubles the time of this loop (the longest thing in an iteration)
+                double cq[8], sq[8], sr[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    cq[u] = cs[q + u];
+                    sq[u] = Sb[(t + 1) + (q + u) * LS];
+                    sr[u] = Sb[r + (q + u) * LS];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                p0 = fma(-(cq[0] * sq[0]), sr[0], p0);
+                p1 = fma(-(cq[1] * sq[1]), sr[1], p1);
+                p2 = fma(-(cq[2] * sq[2]), sr[2], p2);
+                p3 = fma(-(cq[3] * sq[3]), sr[3], p3);
+                p0 = fma(-(cq[4] * sq[4]), sr[4], p0);
+                p1 = fma(-(cq[5] * sq[5]), sr[5], p1);
+                p2 = fma(-(cq[6] * sq[6]), sr[6], p2);
+                p3 = fma(-(cq[7] * sq[7]), sr[7], p3);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             for (; q + 4 <= t; q += 4) {
                 p0 = fma(-(cs[q] * Sb[(t + 1) + q * LS]), Sb[r + q * LS], p0);
                 p1 = fma(-(cs[q + 1] * Sb[(t + 1) + (q + 1) * LS]), Sb[r + (q + 1) * LS], p1);
@@ -238,7 +266,7 @@ __global__ __launch_bounds__(1024) void ep_lml_kernel(int n, int np, const doubl
     if (threadIdx.x == 0) out[0] = red[0];
 }
 
-constexpr int EP_BLOCK_LDS = (GP_NB * (GP_NB + 1) + 3 * GP_NB + 8) * (int)sizeof(double);
+constexpr int EP_BLOCK_LDS = (GP_NB * (GP_NB + 1) + 5 * GP_NB + 8) * (int)sizeof(double);
 inline dim3 g1(int n) { return dim3((n + 255) / 256); }
 
 // end of sweep: L, Sigma, mu from the current site parameters (EpParameterEstimator.scala:56-61)
