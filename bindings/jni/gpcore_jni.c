@@ -107,6 +107,23 @@ JNIEXPORT void JNICALL Java_gpcore_Native_lmlGradBatched(JNIEnv *env, jclass k, 
     if (st != GP_OK) throw_for(env, CTX(h), st, 0);
 }
 
+/* GpPredictor.obtainOptimalHyperParams: thetaInOut holds theta0 on entry and the best-seen point on return; returns its LML */
+JNIEXPORT jdouble JNICALL Java_gpcore_Native_optimizeRbf(JNIEnv *env, jclass k, jlong h, jdoubleArray x, jint n, jint d, jint ldx,
+                                                         jdoubleArray y, jdoubleArray thetaInOut, jint nparams, jdouble sigmaNoiseOrNaN,
+                                                         jint maxIter, jint history) {
+    double *X = (*env)->GetPrimitiveArrayCritical(env, x, NULL);
+    double *Y = (*env)->GetPrimitiveArrayCritical(env, y, NULL);
+    double *T = (*env)->GetPrimitiveArrayCritical(env, thetaInOut, NULL);
+    double theta0[66], lml = 0.0;
+    for (int i = 0; i < d + 2 && i < 66; ++i) theta0[i] = T[i];
+    gp_status st = gp_optimize_rbf(CTX(h), X, n, d, ldx, Y, theta0, nparams, sigmaNoiseOrNaN, maxIter, history, T, &lml, NULL, NULL);
+    (*env)->ReleasePrimitiveArrayCritical(env, thetaInOut, T, 0);
+    (*env)->ReleasePrimitiveArrayCritical(env, y, Y, JNI_ABORT);
+    (*env)->ReleasePrimitiveArrayCritical(env, x, X, JNI_ABORT);
+    if (st != GP_OK) throw_for(env, CTX(h), st, 0);
+    return lml;
+}
+
 /* breeze.linalg.cholesky / MatrixUtils.forwardSolve, backSolve, invTriangular */
 JNIEXPORT void JNICALL Java_gpcore_Native_potrfLower(JNIEnv *env, jclass k, jlong h, jdoubleArray a, jint off, jint n, jint lda) {
     double *A = (*env)->GetPrimitiveArrayCritical(env, a, NULL);

@@ -50,6 +50,16 @@ class GpPredictor(val kernelFunc: KernelFunc) {
       hyperParams.toDenseVector.toArray, 1, optimizedParamsNum, input.sigmaNoise.getOrElse(Double.NaN), lml, grad, info)
     (lml(0), DenseVector(grad))
   }
+
+  // GpPredictor.scala:126-142 -- BreezeLbfgsOptimizer(maxIter = 20), m = 4, best-seen point; optimizeNoise = false keeps sn fixed
+  def obtainOptimalHyperParams(trainingData: DenseMatrix[Double], sigmaNoise: Option[Double], targets: DenseVector[Double],
+                               optimizeNoise: Boolean): KernelFuncHyperParams = {
+    val x = compact(trainingData)
+    val theta = kernelFunc.hyperParams.toDenseVector.toArray
+    Native.optimizeRbf(Native.defaultCtx, x.data, x.rows, x.cols, x.majorStride, targets.toArray, theta,
+      if (optimizeNoise) theta.length else theta.length - 1, sigmaNoise.getOrElse(Double.NaN), 20, 4)
+    kernelFunc.hyperParams.fromDenseVector(DenseVector(theta))
+  }
 }
 
 object GpPredictor {

@@ -146,6 +146,21 @@ class Context:
                                                      L.dptr(lml), L.dptr(grad), info.ctypes.data_as(C.POINTER(C.c_int))))
         return lml, grad[:, :nparams], info
 
+    def optimize_rbf(self, X, y, theta0, nparams=None, sigma_noise=None, max_iter=20, history=4):
+        """gp_optimize_rbf: (theta*, LML(theta*), iterations, evaluations)."""
+        X, y = L.f64(X), L.f64(y)
+        n, d = X.shape
+        theta0 = np.ascontiguousarray(theta0, dtype=np.float64)
+        if theta0.size != d + 2 or y.size != n:
+            raise ValueError("dimension mismatch")
+        nparams = d + 2 if nparams is None else int(nparams)
+        out, lml = np.zeros(d + 2), np.zeros(1)
+        its, evs = C.c_int(0), C.c_int(0)
+        sn = float("nan") if sigma_noise is None else float(sigma_noise)
+        self.check(self._lib.gp_optimize_rbf(self.h, L.dptr(X), n, d, n, L.dptr(y), L.dptr(theta0), nparams, sn, int(max_iter), int(history),
+                                             L.dptr(out), L.dptr(lml), C.byref(its), C.byref(evs)))
+        return out, float(lml[0]), its.value, evs.value
+
 
 class RegressionModel:
     """(L, alpha, LML) of GpPredictor.preComputeComponents, resident on the GPU."""

@@ -1015,5 +1015,131 @@ extern "C" gp_status gp_lml_grad_rbf_batched(gp_ctx *ctx, const double *X, int n
 }
 
 // ------------------------------------------------------------------------------------------------
+// GpPredictor.obtainOptimalHyperParams (gp/regression/GpPredictor.scala:126-142) driving
+// BreezeLbfgsOptimizer.maximize (optimization/Optimization.scala:30-63): L-BFGS with `history` correction pairs and at
+// most max_iter iterations on f(x) = -LML over the first nparams entries of theta (vector order), returning the best point
+// any evaluation saw (:44-46,52-55).  Breeze's LBFGS is third-party code outside the reference tree, so its exact iterates
+// are not reproducible: what is kept is the interface, the memory/iteration limits, the objective and the
+// best-seen rule.  The line search is batched: the NC trial steps alpha0 * 2^-c of one iteration are ONE lockstep group on
+// the device (training data stays resident for the whole run), so an iteration costs one group evaluation however many
+// trial steps the Armijo test rejects.
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct lbfgs_pair { std::vector<double> s, y; double rho; };
+
+double vdot(const std::vector<double> &a, const std::vector<double> &b) {
+    double r = 0.0;
+    for (size_t i = 0; i < a.size(); ++i) r += a[i] * b[i];
+    return r;
+}
+
+}  // namespace
+
+extern "C" gp_status gp_optimize_rbf(gp_ctx *ctx, const double *X, int n, int d, int ldx, const double *y, const double *theta0, int nparams,
+                                     double sigma_noise, int max_iter, int history, double *theta_out, double *lml_out, int *iters_out,
+                                     int *evals_out) {
+    if (!ctx) return GP_EINVAL;
+    GP_REQUIRE(ctx, X && y && theta0 && theta_out, "null pointer");
+    GP_REQUIRE(ctx, n >= 1 && d >= 1 && d <= 64 && ldx >= n, "bad dimensions");
+    const int P = d + 2;
+    GP_REQUIRE(ctx, nparams >= 1 && nparams <= P && max_iter >= 0 && history >= 1, "1 <= nparams <= d+2, max_iter >= 0, history >= 1");
+    GP_HIP(ctx, hipSetDevice(ctx->device));
+    constexpr int NC = 6;   // trial steps per iteration: alpha0, alpha0/2, ..., alpha0/32
+    lml_worker w;
+    w.ctx = ctx;
+    w.G = NC;
+    GP_TRY(lml_worker_setup(w, X, n, d, ldx, y, nparams));
+
+    std::vector<double> theta(theta0, theta0 + P), thetas((size_t)NC * P), fl(NC), gl((size_t)NC * nparams);
+    std::vector<int> infos(NC);
+    int evals = 0;
+    // f = -LML, g = -grad at `count` settings; non-PD settings come back as +inf
+    auto evaluate = [&](int count) -> gp_status {
+        GP_TRY(lml_worker_eval(w, thetas.data(), count, nparams, sigma_noise, fl.data(), gl.data(), infos.data()));
+        evals += count;
+        for (int c = 0; c < count; ++c) {
+            bool bad = infos[c] != 0 || !std::isfinite(fl[c]);
+            for (int p = 0; p < nparams && !bad; ++p) bad = !std::isfinite(gl[(size_t)c * nparams + p]);
+            fl[c] = bad ? INFINITY : -fl[c];
+            for (int p = 0; p < nparams; ++p) gl[(size_t)c * nparams + p] = bad ? 0.0 : -gl[(size_t)c * nparams + p];
+        }
+        return GP_OK;
+    };
+    std::copy(theta.begin(), theta.end(), thetas.begin());
+    GP_TRY(evaluate(1));
+    if (!std::isfinite(fl[0])) { GP_SET_ERR(ctx, "the starting hyper-parameters do not give a positive definite matrix (pivot %d)", infos[0]); return GP_ENOTPD; }
+    std::vector<double> x(theta.begin(), theta.begin() + nparams), g(gl.begin(), gl.begin() + nparams);
+    double f = fl[0];
+    std::vector<double> best_x = x;
+    double best_f = f;
+    std::vector<lbfgs_pair> hist;
+    int it = 0;
+    for (; it < max_iter; ++it) {
+        const double gnorm = std::sqrt(vdot(g, g));
+        if (gnorm <= 1e-9 * std::max(1.0, std::fabs(f))) break;
+        // two-loop recursion: p = -H g
+        std::vector<double> q = g, al(hist.size());
+        for (int k = (int)hist.size() - 1; k >= 0; --k) {
+            al[k] = hist[k].rho * vdot(hist[k].s, q);
+            for (int i = 0; i < nparams; ++i) q[i] -= al[k] * hist[k].y[i];
+        }
+        double scale = hist.empty() ? 1.0 / gnorm : vdot(hist.back().s, hist.back().y) / vdot(hist.back().y, hist.back().y);
+        for (int i = 0; i < nparams; ++i) q[i] *= scale;
+        for (size_t k = 0; k < hist.size(); ++k) {
+            const double be = hist[k].rho * vdot(hist[k].y, q);
+            for (int i = 0; i < nparams; ++i) q[i] += hist[k].s[i] * (al[k] - be);
+        }
+        std::vector<double> pdir(nparams);
+        for (int i = 0; i < nparams; ++i) pdir[i] = -q[i];
+        double slope = vdot(g, pdir);
+        if (!(slope < 0.0)) {   // not a descent direction: drop the history, steepest descent
+            hist.clear();
+            for (int i = 0; i < nparams; ++i) pdir[i] = -g[i] / gnorm;
+            slope = -gnorm;
+        }
+        // batched backtracking: up to 3 groups of NC halvings
+        int chosen = -1;
+        double alpha0 = 1.0, alpha = 0.0;
+        for (int round = 0; round < 3 && chosen < 0; ++round, alpha0 *= std::ldexp(1.0, -NC)) {
+            for (int c = 0; c < NC; ++c) {
+                const double a = std::ldexp(alpha0, -c);
+                std::copy(theta.begin(), theta.end(), thetas.begin() + (size_t)c * P);
+                for (int i = 0; i < nparams; ++i) thetas[(size_t)c * P + i] = x[i] + a * pdir[i];
+            }
+            GP_TRY(evaluate(NC));
+            for (int c = 0; c < NC; ++c) {
+                if (fl[c] < best_f) { best_f = fl[c]; for (int i = 0; i < nparams; ++i) best_x[i] = thetas[(size_t)c * P + i]; }
+                if (chosen < 0 && fl[c] <= f + 1e-4 * std::ldexp(alpha0, -c) * slope) { chosen = c; alpha = std::ldexp(alpha0, -c); }
+            }
+        }
+        if (chosen < 0) break;   // no trial step decreases f: converged to the resolution of the line search
+        lbfgs_pair pr;
+        pr.s.resize(nparams), pr.y.resize(nparams);
+        for (int i = 0; i < nparams; ++i) {
+            pr.s[i] = alpha * pdir[i];
+            pr.y[i] = gl[(size_t)chosen * nparams + i] - g[i];
+            x[i] += pr.s[i];
+            g[i] = gl[(size_t)chosen * nparams + i];
+        }
+        const double fnew = fl[chosen], sy = vdot(pr.s, pr.y);
+        if (sy > 1e-12 * std::sqrt(vdot(pr.s, pr.s) * vdot(pr.y, pr.y))) {
+            pr.rho = 1.0 / sy;
+            if ((int)hist.size() == history) hist.erase(hist.begin());
+            hist.push_back(pr);
+        }
+        const bool stalled = std::fabs(f - fnew) <= 1e-10 * std::max(1.0, std::fabs(f));
+        f = fnew;
+        if (stalled) { ++it; break; }
+    }
+    std::copy(theta.begin(), theta.end(), theta_out);
+    for (int i = 0; i < nparams; ++i) theta_out[i] = best_x[i];
+    if (lml_out) *lml_out = -best_f;
+    if (iters_out) *iters_out = it;
+    if (evals_out) *evals_out = evals;
+    return GP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // EP classification -- implemented in gpcore_ep.hip
 // ------------------------------------------------------------------------------------------------

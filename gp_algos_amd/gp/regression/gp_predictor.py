@@ -115,8 +115,15 @@ class GpPredictor:
         return float(lml[0]), grad[0].copy()
 
     def obtainOptimalHyperParams(self, trainingData, sigmaNoise, targets, optimizeNoise):   # :126-142
-        optimizer = BreezeLbfgsOptimizer(maxIter=20)
         full = self.kernelFunc.hyperParams.toDenseVector()
+        if optimizeNoise and isinstance(self.kernelFunc, GaussianRbfKernel):
+            # native L-BFGS (gp_optimize_rbf): same objective, memory (m = 4), iteration cap (20) and best-seen rule as
+            # BreezeLbfgsOptimizer; training data stay on the GPU and each line search is one lockstep batch
+            X = np.asfortranarray(np.asarray(trainingData, dtype=np.float64))
+            best, _, _, _ = default_context().optimize_rbf(X, targets, full, nparams=len(full), sigma_noise=sigmaNoise,
+                                                           max_iter=20, history=4)
+            return self.kernelFunc.hyperParams.fromDenseVector(best)
+        optimizer = BreezeLbfgsOptimizer(maxIter=20)
         init = full if optimizeNoise else full[:-1]
 
         def objective(params):

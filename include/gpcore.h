@@ -129,6 +129,14 @@ gp_status gp_predict_dev(gp_model *model, const double *dXs, int m, int ldxs, do
  * lml[B], grad[B x nparams] row-major.  info[B]: 0 or failing pivot per setting (lml = NaN there). */
 gp_status gp_lml_grad_rbf_batched(gp_ctx *ctx, const double *X, int n, int d, int ldx, const double *y, const double *thetas, int B, int nparams, double sigma_noise, double *lml, double *grad, int *info);
 
+/* GpPredictor.obtainOptimalHyperParams, gp/regression/GpPredictor.scala:126-142, through
+ * BreezeLbfgsOptimizer.maximize, optimization/Optimization.scala:30-63 (L-BFGS, m = history = 4, maxIter = 20 there):
+ * maximises the LML over the first nparams entries of theta (optimizeNoise=false <=> nparams = d+1), starting at theta0,
+ * and returns the best point any evaluation saw (:44-46,52-55) in theta_out[d+2] with its LML.  The training data stay in
+ * HBM for the whole run and the trial steps of one line search are evaluated as one lockstep batch.  iters_out / evals_out
+ * (optional) report iterations and LML evaluations.  Iterates are not Breeze's (third-party, not in the reference tree). */
+gp_status gp_optimize_rbf(gp_ctx *ctx, const double *X, int n, int d, int ldx, const double *y, const double *theta0, int nparams, double sigma_noise, int max_iter, int history, double *theta_out, double *lml_out, int *iters_out, int *evals_out);
+
 /* ---- EP binary classification ---------------------------------------------------------------- */
 /* EpParameterEstimator(kernelMatrix, targets, _), gp/classification/EpParameterEstimator.scala:11-12.
  * K is any ready-made n x n Gram matrix, y in {-1,+1}. */

@@ -474,3 +474,60 @@ def test_left_looking_posterior_path_at_small_size(ctx, tmp_path, fold_panel_sol
     tok = r.stdout.split()
     dmean, dvar = float(tok[tok.index("DMEAN") + 1]), float(tok[tok.index("DVAR") + 1])
     assert dmean < 1e-9 and dvar < 1e-9, r.stdout
+
+
+# ---- hyper-parameter optimisation (GpPredictor.obtainOptimalHyperParams, Optimization.scala:30-63) ---------------
+def _opt_problem():
+    rng = np.random.default_rng(11)
+    n, d = 220, 2
+    X = np.asfortranarray(rng.uniform(-2.0, 2.0, size=(n, d)))
+    true = np.array([1.3, 0.8, 1.6, 0.15])
+    K = orc.gram_sym(X, true)
+    y = np.linalg.cholesky(K) @ rng.standard_normal(n)
+    return X, y, true
+
+
+def test_optimize_rbf_reaches_the_lbfgs_optimum(ctx):
+    """Breeze's iterates are not reproducible (third-party): the native optimiser is checked on what the
+    reference's wrapper guarantees -- the returned point is the best one evaluated, it improves on the start -- and against
+    the optimum a reference L-BFGS (scipy, driven by the ORACLE's LML and gradient) reaches from the same start."""
+    from scipy.optimize import minimize
+    X, y, true = _opt_problem()
+    theta0 = np.array([1.0, 1.0, 1.0, 0.3])
+    best, lml, iters, evals = ctx.optimize_rbf(X, y, theta0, max_iter=60, history=4)
+    lml0 = orc.lml_grad(X, y, theta0)[0]
+    o_lml, o_grad = orc.lml_grad(X, y, best)
+    assert abs(lml - o_lml) <= 1e-9 * abs(o_lml)                 # reported value is the LML at the returned point
+    assert lml > lml0 and 1 <= iters <= 60 and evals >= iters
+    res = minimize(lambda t: tuple(-v for v in orc.lml_grad(X, y, t)), theta0, jac=True, method="L-BFGS-B",
+                   options={"maxcor": 4, "maxiter": 200, "ftol": 1e-14, "gtol": 1e-9})
+    assert lml >= -res.fun - 1e-6 * abs(res.fun)
+    assert np.max(np.abs(o_grad)) <= 1e-3 * max(1.0, abs(o_lml))
+    assert np.allclose(np.abs(best), np.abs(res.x), rtol=2e-3, atol=2e-3)   # sf, l, sn enter squared: sign-free
+
+
+def test_optimize_rbf_iteration_cap_subset_and_errors(ctx):
+    X, y, _ = _opt_problem()
+    theta0 = np.array([1.0, 1.0, 1.0, 0.3])
+    lml0 = orc.lml_grad(X, y, theta0)[0]
+    b0, l0, it0, ev0 = ctx.optimize_rbf(X, y, theta0, max_iter=0)
+    assert it0 == 0 and ev0 == 1 and np.array_equal(b0, theta0) and abs(l0 - lml0) <= 1e-10 * abs(lml0)
+    b2, l2, it2, _ = ctx.optimize_rbf(X, y, theta0, max_iter=2)
+    assert it2 <= 2 and l2 > l0
+    b3, l3, _, _ = ctx.optimize_rbf(X, y, theta0, nparams=3, max_iter=20)      # optimizeNoise = false: sn stays put
+    assert b3[3] == theta0[3] and l3 > l0
+    from gp_algos_amd._lib import NotPositiveDefinite
+    with pytest.raises(ValueError):
+        ctx.optimize_rbf(X, y, theta0, nparams=0)
+    with pytest.raises(NotPositiveDefinite):
+        ctx.optimize_rbf(X, y, theta0, sigma_noise=-5.0)   # K - 5 I at the starting point: not PD
+
+
+def test_predictor_mirror_uses_native_optimizer(ctx):
+    from gp_algos_amd.gp.regression.gp_predictor import GpPredictor
+    from gp_algos_amd.utils.kernel_requisites import GaussianRbfKernel, GaussianRbfParams
+    X, y, _ = _opt_problem()
+    kf = GaussianRbfKernel(GaussianRbfParams(1.0, np.array([1.0, 1.0]), 0.3))
+    hp = GpPredictor(kf).obtainOptimalHyperParams(X, None, y, True)
+    got = hp.toDenseVector()
+    assert orc.lml_grad(X, y, got)[0] > orc.lml_grad(X, y, np.array([1.0, 1.0, 1.0, 0.3]))[0]
