@@ -155,6 +155,10 @@ def run_secondary(args):
     gdist.barrier()
 
 
+PMC_SUMMARY = "r01_d_pmc_c2_summary.json"
+DOMINANT_KERNEL = "gemm_nt_f64_kernel<0,0,8,1>"
+
+
 def cpu_opt_baseline(p, sample_pts=4096):
     """Optimised-CPU comparator (numpy/scipy on multithreaded LAPACK, all host cores): vectorised Gram, cho_factor,
     cho_solve, solve_triangular on a bounded sample of the test points.  This is the figure the north-star's
@@ -296,9 +300,9 @@ def main():
         # per the gfx950 correction); only reported for the configuration those passes ran.
         traffic = None
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_b_pmc_c2_summary.json")))
+            pm = json.load(open(os.path.join(ROOT, "profiles", PMC_SUMMARY)))
             if (n, d, m) == (8192, 8, 65536):
-                traffic = pm["kernels"]["gemm_nt_f64_kernel<0>"]["hbm_bytes_per_launch_corrected"]
+                traffic = pm["kernels"][DOMINANT_KERNEL]["hbm_bytes_per_launch_corrected"]
         except Exception:
             traffic = None
         ms_per_step = dt / args.steps * 1e3
@@ -313,11 +317,13 @@ def main():
             "config": {"workload": "C2: GP regression, ARD-RBF, n=%d d=%d fp64, Gram + Cholesky + posterior mean/variance at m=%d "
                                    "test points per GPU" % (n, d, m), "n": n, "d": d, "m_per_gpu": m,
                        "parallelism": "test points sharded %d-way, model refit per rank, no data-path collective" % world},
-            "roofline": {"kernel": "gemm_nt_f64_kernel<0> (posterior solve Vt_i -= Vt_<i L_i,<i^T, v_mfma_f64_16x16x4_f64)",
+            "roofline": {"kernel": DOMINANT_KERNEL + " (posterior step Vt_i = Vt[:, :128(i+1)] Lw_i^T: update and panel solve of block "
+                                   "column i in one product, row reductions in the epilogue; v_mfma_f64_16x16x4_f64)",
                          "bound": "mfma", "achieved": gemm_tflops, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": gemm_tflops / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic,
-                         "traffic_unit": "HBM bytes per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_b_pmc_c2_summary.json)",
-                         "algorithmic_bytes_per_launch": 8.0 * (m * (n / 2.0) + 128 * (n / 2.0) + 2.0 * m * 128),
+                         "traffic_unit": "HBM bytes per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/%s)" % PMC_SUMMARY,
+                         # average over the n/128 launches, K_i = 128 (i + 1): A read m K, Lw block row read 128 K, C written m 128
+                         "algorithmic_bytes_per_launch": 8.0 * (m * ((n + 128) / 2.0) + 128 * ((n + 128) / 2.0) + m * 128),
                          "launches": g_k, "avg_launch_us": g_ms / max(g_k, 1) * 1e3,
                          "flops_per_launch_avg": g_work / max(g_k, 1)},
             "cholesky": {"fit_ms": t_fit * 1e3, "total_tflops": (n ** 3 / 3.0) / t_fit / 1e12,
