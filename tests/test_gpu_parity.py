@@ -255,6 +255,28 @@ def test_lml_grad_flags_non_pd_setting(ctx):
     assert info[1] > 0 and np.isnan(lml[1])
 
 
+def test_lml_grad_many_settings_ragged_groups(ctx):
+    """37 settings: two lockstep groups of 16 on two workers plus a ragged rest, one setting inside a group not positive
+    definite (its group mates must be unaffected), n not a multiple of 128; every setting against the oracle."""
+    p = _problem(150, 3, 0, seed=5)
+    Xdup = np.asfortranarray(np.vstack([p["X"], p["X"][:20]]))       # 20 duplicated rows: singular without noise
+    y = np.concatenate([p["y"], p["y"][:20]])
+    rng = np.random.default_rng(3)
+    thetas = p["theta"][None, :] * rng.uniform(0.6, 1.7, size=(37, p["theta"].size))
+    thetas[21, -1] = 0.0
+    lml, grad, info = ctx.lml_grad_batched(Xdup, y, thetas)
+    assert info[21] > 0 and np.isnan(lml[21]) and np.all(np.isnan(grad[21]))
+    for b in range(37):
+        if b == 21:
+            continue
+        ol, og = orc.lml_grad(Xdup, y, thetas[b])
+        assert info[b] == 0
+        assert abs(lml[b] - ol) <= TOL_LML * abs(ol), b
+        assert np.max(np.abs(grad[b] - og)) <= TOL_GRAD * np.max(np.abs(og)), b
+    one, gone, _ = ctx.lml_grad_batched(Xdup, y, thetas[30:31])         # a group of one gives the same bits
+    assert one[0] == lml[30] and np.array_equal(gone[0], grad[30])
+
+
 # ---- EP binary classification (EpParameterEstimator / GpClassifier) -----------------------------
 TOL_EP = 1e-8        # relative, site parameters after a fixed number of sweeps
 TOL_PROB = 1e-9      # absolute, class-1 probabilities
