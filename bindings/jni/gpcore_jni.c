@@ -124,6 +124,26 @@ JNIEXPORT jdouble JNICALL Java_gpcore_Native_optimizeRbf(JNIEnv *env, jclass k, 
     return lml;
 }
 
+/* MeshHyperParamsLogLikelihoodEvaluator over the leaves of the grid: EP LML per setting, by setting index */
+JNIEXPORT void JNICALL Java_gpcore_Native_epLmlRbfBatched(JNIEnv *env, jclass k, jlong h, jdoubleArray x, jint n, jint d, jint ldx,
+                                                          jintArray y, jdoubleArray thetas, jint B, jdouble stopEps, jint maxSweeps,
+                                                          jboolean strict, jdoubleArray lml, jintArray sweeps, jintArray info) {
+    double *X = (*env)->GetPrimitiveArrayCritical(env, x, NULL);
+    jint *Y = (*env)->GetPrimitiveArrayCritical(env, y, NULL);
+    double *T = (*env)->GetPrimitiveArrayCritical(env, thetas, NULL);
+    double *L = (*env)->GetPrimitiveArrayCritical(env, lml, NULL);
+    jint *S = (*env)->GetPrimitiveArrayCritical(env, sweeps, NULL);
+    jint *I = (*env)->GetPrimitiveArrayCritical(env, info, NULL);
+    gp_status st = gp_ep_lml_rbf_batched(CTX(h), X, n, d, ldx, (const int32_t *)Y, T, B, stopEps, maxSweeps, strict ? 1 : 0, L, (int *)S, (int *)I);
+    (*env)->ReleasePrimitiveArrayCritical(env, info, I, 0);
+    (*env)->ReleasePrimitiveArrayCritical(env, sweeps, S, 0);
+    (*env)->ReleasePrimitiveArrayCritical(env, lml, L, 0);
+    (*env)->ReleasePrimitiveArrayCritical(env, thetas, T, JNI_ABORT);
+    (*env)->ReleasePrimitiveArrayCritical(env, y, Y, JNI_ABORT);
+    (*env)->ReleasePrimitiveArrayCritical(env, x, X, JNI_ABORT);
+    if (st != GP_OK) throw_for(env, CTX(h), st, 0);
+}
+
 /* breeze.linalg.cholesky / MatrixUtils.forwardSolve, backSolve, invTriangular */
 JNIEXPORT void JNICALL Java_gpcore_Native_potrfLower(JNIEnv *env, jclass k, jlong h, jdoubleArray a, jint off, jint n, jint lda) {
     double *A = (*env)->GetPrimitiveArrayCritical(env, a, NULL);

@@ -10,6 +10,7 @@ object Native {
   @native def modelGet(ctx: Long, model: Long, what: Int, out: Array[Double], ld: Int): Unit
   @native def modelDestroy(model: Long): Unit
   @native def predict(ctx: Long, model: Long, xs: Array[Double], xsoff: Int, m: Int, ldxs: Int, mean: Array[Double], variance: Array[Double], cov: Array[Double]): Unit
+  @native def epLmlRbfBatched(ctx: Long, x: Array[Double], n: Int, d: Int, ldx: Int, y: Array[Int], thetas: Array[Double], b: Int, stopEps: Double, maxSweeps: Int, strict: Boolean, lml: Array[Double], sweeps: Array[Int], info: Array[Int]): Unit
   @native def optimizeRbf(ctx: Long, x: Array[Double], n: Int, d: Int, ldx: Int, y: Array[Double], thetaInOut: Array[Double], nparams: Int, sigmaNoiseOrNaN: Double, maxIter: Int, history: Int): Double
   @native def lmlGradBatched(ctx: Long, x: Array[Double], n: Int, d: Int, ldx: Int, y: Array[Double], thetas: Array[Double], b: Int, nparams: Int, sigmaNoiseOrNaN: Double, lml: Array[Double], grad: Array[Double], info: Array[Int]): Unit
   @native def potrfLower(ctx: Long, a: Array[Double], off: Int, n: Int, lda: Int): Unit

@@ -146,6 +146,21 @@ class Context:
                                                      L.dptr(lml), L.dptr(grad), info.ctypes.data_as(C.POINTER(C.c_int))))
         return lml, grad[:, :nparams], info
 
+    def ep_lml_rbf_batched(self, X, y, thetas, stop_eps=0.01, max_sweeps=1000, strict=True):
+        """gp_ep_lml_rbf_batched: (lml[B], sweeps[B], info[B])."""
+        X = L.f64(X)
+        n, d = X.shape
+        yi = np.ascontiguousarray(y, dtype=np.int32).reshape(-1)
+        thetas = np.ascontiguousarray(np.atleast_2d(thetas), dtype=np.float64)
+        B, P = thetas.shape
+        if P != d + 2 or yi.size != n:
+            raise ValueError("dimension mismatch")
+        lml, sw, info = np.zeros(B), np.zeros(B, dtype=np.int32), np.zeros(B, dtype=np.int32)
+        self.check(self._lib.gp_ep_lml_rbf_batched(self.h, L.dptr(X), n, d, n, yi.ctypes.data_as(C.POINTER(C.c_int32)), L.dptr(thetas), B,
+                                                   float(stop_eps), int(max_sweeps), int(bool(strict)), L.dptr(lml),
+                                                   sw.ctypes.data_as(C.POINTER(C.c_int)), info.ctypes.data_as(C.POINTER(C.c_int))))
+        return lml, sw, info
+
     def optimize_rbf(self, X, y, theta0, nparams=None, sigma_noise=None, max_iter=20, history=4):
         """gp_optimize_rbf: (theta*, LML(theta*), iterations, evaluations)."""
         X, y = L.f64(X), L.f64(y)

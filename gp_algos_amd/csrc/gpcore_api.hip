@@ -351,6 +351,16 @@ void gpi_solve_rows_lower(gp_ctx *ctx, double *Vt, int mp, const double *L, int 
                           const double *tvec, double *dots) { solve_rows_lower(ctx, Vt, mp, L, np, ldl, dinv, sumsq, tvec, dots); }
 void gpi_inverse_transpose_lower(gp_ctx *ctx, double *T, const double *L, int np, int ldl, const double *dinv) { inverse_transpose_lower(ctx, T, L, np, ldl, dinv); }
 void gpi_back_solve_vec(gp_ctx *ctx, const double *L, int np, int ldl, const double *dinv, double *z, double *alpha) { back_solve_vec(ctx, L, np, ldl, dinv, z, alpha); }
+// k-th helper context of `ctx` (same device, own stream and workspaces), created on first use and destroyed with it
+gp_ctx *gpi_child_ctx(gp_ctx *ctx, int k) {
+    ctx_ext *x = ext_of(ctx);
+    while ((int)x->children.size() <= k) {
+        gp_ctx *c = nullptr;
+        if (gp_ctx_create(ctx->device, nullptr, &c) != GP_OK) return nullptr;
+        x->children.push_back(c);
+    }
+    return x->children[k];
+}
 // z <- L^-1 t (t is consumed): one fused launch per block step
 void gpi_forward_solve_vec(gp_ctx *ctx, const double *L, int np, int ldl, const double *dinv, double *t, double *z) {
     for (int k = 0; k < np / GP_NB; ++k)

@@ -14,7 +14,12 @@
 // the blocked Cholesky, the row-panel solve and the MFMA syrk of the regression path.
 #include "gpcore_internal.h"
 
+#include <algorithm>
+#include <atomic>
+#include <cmath>
 #include <new>
+#include <thread>
+#include <vector>
 
 struct gp_ep {
     gp_ctx *ctx = nullptr;
@@ -296,14 +301,9 @@ gp_status ep_refactor(gp_ep *ep) {
     return GP_OK;
 }
 
-}  // namespace
-
-extern "C" {
-
-gp_status gp_ep_create(gp_ctx *ctx, const double *K, int n, int ldk, const int32_t *y, gp_ep **out) {
-    if (!ctx || !out) return GP_EINVAL;
+// device buffers + labels; K is left for the caller to fill (host upload or device Gram), then ep_start()
+gp_status ep_alloc(gp_ctx *ctx, int n, const int32_t *y, gp_ep **out) {
     *out = nullptr;
-    GP_REQUIRE(ctx, K && y && n >= 1 && ldk >= n, "bad arguments");   // require(kernelMatrix.rows == targets.length)
     for (int i = 0; i < n; ++i) GP_REQUIRE(ctx, y[i] == 1 || y[i] == -1, "targets must contain values from set {-1,1}");
     GP_HIP(ctx, hipSetDevice(ctx->device));
     GP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(ep_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, EP_BLOCK_LDS));
@@ -324,16 +324,40 @@ gp_status gp_ep_create(gp_ctx *ctx, const double *K, int n, int ldk, const int32
     hipStream_t s = ctx->stream;
     if (e == hipSuccess) e = hipMemsetAsync(ep->K, 0, nn, s);
     if (e == hipSuccess) e = hipMemsetAsync(ep->L, 0, nn, s);
-    if (e == hipSuccess) e = hipMemsetAsync(ep->vec, 0, 10 * np * sizeof(double), s);
-    if (e == hipSuccess) e = hipMemsetAsync(ep->cvec, 0, 2 * GP_NB * sizeof(double), s);
     if (e == hipSuccess) e = hipMemsetAsync(ep->y, 0, np * sizeof(int), s);
     if (e == hipSuccess) e = hipMemcpyAsync(ep->y, y, n * sizeof(int), hipMemcpyHostToDevice, s);
     if (e != hipSuccess) { GP_SET_ERR(ctx, "EP allocation (n=%d) failed: %s", n, hipGetErrorString(e)); gp_ep_destroy(ep); return GP_ENOMEM; }
+    *out = ep;
+    return GP_OK;
+}
+
+// (re)start EP on the Gram matrix now in ep->K (rows/cols < n): zero site parameters, Sigma = K  (:32-38)
+gp_status ep_start(gp_ep *ep) {
+    gp_ctx *ctx = ep->ctx;
+    hipStream_t s = ctx->stream;
+    GP_HIP(ctx, hipMemsetAsync(ep->vec, 0, 10 * (size_t)ep->np * sizeof(double), s));
+    GP_HIP(ctx, hipMemsetAsync(ep->cvec, 0, 2 * GP_NB * sizeof(double), s));
+    gpk_pad_identity(s, ep->K, ep->n, ep->np, ep->np);
+    gpk_copy_2d(s, ep->Sig, ep->np, ep->K, ep->np, ep->np, ep->np);   // sigmaMatrix = kernelMatrix.copy (:35)
+    ep->sweeps = 0;
+    GP_HIP(ctx, hipStreamSynchronize(s));
+    return GP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+gp_status gp_ep_create(gp_ctx *ctx, const double *K, int n, int ldk, const int32_t *y, gp_ep **out) {
+    if (!ctx || !out) return GP_EINVAL;
+    *out = nullptr;
+    GP_REQUIRE(ctx, K && y && n >= 1 && ldk >= n, "bad arguments");   // require(kernelMatrix.rows == targets.length)
+    gp_ep *ep = nullptr;
+    GP_TRY(ep_alloc(ctx, n, y, &ep));
     gp_status st = gpi_upload_2d(ctx, ep->K, ep->np, K, ldk, n, n);
     if (st != GP_OK) { gp_ep_destroy(ep); return st; }
-    gpk_pad_identity(s, ep->K, n, ep->np, ep->np);
-    gpk_copy_2d(s, ep->Sig, ep->np, ep->K, ep->np, ep->np, ep->np);   // sigmaMatrix = kernelMatrix.copy (:35)
-    GP_HIP(ctx, hipStreamSynchronize(s));
+    st = ep_start(ep);
+    if (st != GP_OK) { gp_ep_destroy(ep); return st; }
     *out = ep;
     return GP_OK;
 }
@@ -492,6 +516,85 @@ gp_status gp_ep_predict(gp_ep *ep, const double *Ks, int m, int ldks, const doub
     gpi_solve_rows_lower(ctx, Vt, mp, ep->L, np, np, ep->dinv, sumsq, nullptr, nullptr);
     hipLaunchKernelGGL(ep_prob_kernel, g1(m), dim3(256), 0, s, dout + mp, dout, sumsq, dk, m);
     return gpi_download_2d(ctx, prob, m, dout + mp, m, m, 1);
+}
+
+// EP log marginal likelihood at B hyper-parameter settings of the ARD-RBF kernel: what
+// MeshHyperParamsLogLikelihoodEvaluator.recEvaluate (gp/classification/MeshHyperParamsLogLikelihoodEvaluator.scala:26-40) asks of
+// MarginalLikelihoodEvaluator.logLikelihoodWithoutGrad (MarginalLikelihoodEvaluator.scala:24-31) one setting at a time, returned by
+// setting index (the reference's map is mis-keyed).  Per setting: Gram on the device, EP sweeps until
+// AvgBasedStopCriterion(stop_eps) holds (EpParameterEstimator.scala:187-202; sweep 0 always runs; stop_eps < 0: exactly
+// max_sweeps sweeps), EP LML (strict: as compiled).  Settings are independent: a few run concurrently, each on its own context.
+gp_status gp_ep_lml_rbf_batched(gp_ctx *ctx, const double *X, int n, int d, int ldx, const int32_t *y, const double *thetas, int B,
+                                double stop_eps, int max_sweeps, int strict, double *lml, int *sweeps, int *info) {
+    if (!ctx) return GP_EINVAL;
+    GP_REQUIRE(ctx, X && y && thetas && lml, "null pointer");
+    GP_REQUIRE(ctx, n >= 1 && d >= 1 && d <= 64 && ldx >= n && B >= 0 && max_sweeps >= 1, "bad dimensions");
+    if (B == 0) return GP_OK;
+    const int P = d + 2;
+    int nw = 3;
+    if (const char *e = getenv("GPCORE_EP_WORKERS")) nw = atoi(e);
+    nw = std::max(1, std::min(std::min(nw, 8), B));
+    std::vector<gp_ctx *> ctxs(nw, nullptr);
+    ctxs[0] = ctx;
+    for (int k = 1; k < nw; ++k) {
+        ctxs[k] = gpi_child_ctx(ctx, k - 1);
+        if (!ctxs[k]) { nw = k; break; }
+    }
+    std::vector<gp_status> sts(nw, GP_OK);
+    std::atomic<int> next{0};
+    auto run = [&](int k) {
+        gp_ctx *c = ctxs[k];
+        gp_ep *ep = nullptr;
+        gp_status st = ep_alloc(c, n, y, &ep);
+        double *dX = nullptr;
+        if (st == GP_OK) st = gpi_ws_get(c, WS_A, sizeof(double) * (size_t)n * d, &dX);
+        if (st == GP_OK) st = gpi_upload_2d(c, dX, n, X, ldx, n, d);
+        std::vector<double> tau(n), nu(n), tau_old(n), nu_old(n);
+        while (st == GP_OK) {
+            const int b = next.fetch_add(1);
+            if (b >= B) break;
+            gpk_gram_sym(c->stream, dX, n, d, n, thetas + (size_t)b * P, ep->K, ep->np, 1, 0.0);
+            st = ep_start(ep);
+            int j = 0, h = 0;
+            std::fill(tau.begin(), tau.end(), 0.0);
+            std::fill(nu.begin(), nu.end(), 0.0);
+            gp_status es = GP_OK;
+            while (st == GP_OK && es == GP_OK) {
+                tau_old = tau, nu_old = nu;
+                es = gp_ep_sweep(ep, 1, tau.data(), nu.data(), &h);
+                if (es != GP_OK) break;
+                ++j;
+                if (j >= max_sweeps) break;
+                if (stop_eps >= 0.0) {   // avgBetweenSiteParams :195-202: (sum / 2) * n, precedence as written
+                    double sum = 0.0;
+                    for (int i = 0; i < n; ++i) sum = sum + (nu[i] - nu_old[i]) + (tau[i] - tau_old[i]);
+                    if (std::fabs(sum / 2 * n) < stop_eps) break;
+                }
+            }
+            if (es == GP_ENOTPD) {
+                lml[b] = NAN;
+                if (info) info[b] = h;
+            } else if (es != GP_OK) {
+                st = es;
+            } else if (st == GP_OK) {
+                st = gp_ep_lml(ep, strict, lml + b);
+                if (info) info[b] = 0;
+            }
+            if (sweeps) sweeps[b] = j;
+        }
+        if (ep) gp_ep_destroy(ep);
+        sts[k] = st;
+    };
+    std::vector<std::thread> threads;
+    for (int k = 1; k < nw; ++k) threads.emplace_back(run, k);
+    run(0);
+    for (auto &t : threads) t.join();
+    for (int k = 0; k < nw; ++k)
+        if (sts[k] != GP_OK) {
+            if (k > 0) GP_SET_ERR(ctx, "%s", ctxs[k]->err);
+            return sts[k];
+        }
+    return GP_OK;
 }
 
 void gp_ep_destroy(gp_ep *ep) {

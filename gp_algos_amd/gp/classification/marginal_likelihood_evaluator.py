@@ -7,7 +7,8 @@ import numpy as np
 
 from ...utils import matrix_utils
 from ...utils.kernel_requisites import GaussianRbfKernel
-from .ep_parameter_estimator import EpParameterEstimator
+from ... import default_context
+from .ep_parameter_estimator import AvgBasedStopCriterion, EpParameterEstimator, FixedSweepsStopCriterion
 
 
 class MarginalLikelihoodEvaluator:
@@ -49,5 +50,18 @@ class MeshHyperParamsLogLikelihoodEvaluator:
 
     def evaluate(self, hyperParamsRanges, trainData, targets):
         settings = [np.array(t, dtype=np.float64) for t in itertools.product(*[list(r) for r in hyperParamsRanges])]
-        values = [self.likelihoodEvaluator.logLikelihoodWithoutGrad(trainData, targets, th) for th in settings]
+        ev = self.likelihoodEvaluator
+        stop = ev.stopCriterion
+        if isinstance(ev.kernelFunc, GaussianRbfKernel) and isinstance(stop, (AvgBasedStopCriterion, FixedSweepsStopCriterion)):
+            # one C-ABI call for the whole grid: Gram, EP sweeps and LML of every setting stay on the GPU
+            eps, cap = (stop.eps, 1000) if isinstance(stop, AvgBasedStopCriterion) else (-1.0, stop.sweeps)
+            X = np.asfortranarray(np.asarray(trainData, dtype=np.float64))
+            values, _, info = default_context().ep_lml_rbf_batched(X, targets, np.stack(settings), stop_eps=eps, max_sweeps=cap,
+                                                                  strict=ev.strict)
+            if np.any(info != 0):
+                from ..._lib import NotPositiveDefinite
+                b = int(np.flatnonzero(info)[0])
+                raise NotPositiveDefinite(2, "setting %d: I + S^1/2 K S^1/2 not positive definite at pivot %d" % (b, info[b]), int(info[b]))
+            return settings, values
+        values = [ev.logLikelihoodWithoutGrad(trainData, targets, th) for th in settings]
         return settings, np.array(values)

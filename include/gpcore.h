@@ -159,6 +159,14 @@ gp_status gp_ep_get(gp_ep *ep, int what, double *out, int ld);
 /* GpClassifier.classify, gp/classification/GpClassifier.scala:24-47: Ks is m x n (test-train),
  * kss_diag[m] the diagonal of the test Gram matrix; prob[m] = Phi(mu*_i / sqrt(1 + var*_i)). */
 gp_status gp_ep_predict(gp_ep *ep, const double *Ks, int m, int ldks, const double *kss_diag, double *prob);
+/* EP log marginal likelihood over B ARD-RBF hyper-parameter settings (thetas B x (d+2) row-major), by setting index:
+ * MeshHyperParamsLogLikelihoodEvaluator.recEvaluate, gp/classification/MeshHyperParamsLogLikelihoodEvaluator.scala:26-40, calling
+ * MarginalLikelihoodEvaluator.logLikelihoodWithoutGrad, gp/classification/MarginalLikelihoodEvaluator.scala:24-31, per setting
+ * (Gram -> EpParameterEstimator.estimateSiteParams -> epMarginalLikelihood).  Sweeps run until
+ * AvgBasedStopCriterion(stop_eps) holds (EpParameterEstimator.scala:187-202, checked before every sweep but the first) or
+ * max_sweeps is reached; stop_eps < 0 runs exactly max_sweeps.  lml[B]; sweeps[B] and info[B] optional (info: 0, or the
+ * failing pivot of I + S^1/2 K S^1/2 with lml = NaN).  The reference's mis-keyed result map is not replicated. */
+gp_status gp_ep_lml_rbf_batched(gp_ctx *ctx, const double *X, int n, int d, int ldx, const int32_t *y, const double *thetas, int B, double stop_eps, int max_sweeps, int strict, double *lml, int *sweeps, int *info);
 void gp_ep_destroy(gp_ep *ep);
 
 #ifdef __cplusplus

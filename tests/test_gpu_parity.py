@@ -395,6 +395,54 @@ def test_marginal_likelihood_evaluator_mirror(ctx):
     assert ev2.logLikelihoodWithoutGrad(p["X"], y, p["theta"]) == lml
 
 
+@pytest.mark.parametrize("strict", [True, False])
+def test_ep_lml_batched_over_settings_vs_oracle(ctx, strict):
+    """gp_ep_lml_rbf_batched (mesh evaluation): every setting against the oracle's literal EP run with the same
+    AvgBasedStopCriterion -- same sweep count, same LML; results come back by setting index."""
+    p, _, y = _ep_problem(150, seed=33)
+    base = p["theta"]
+    thetas = np.stack([base * np.concatenate(([a], b * np.ones(3), [1.0])) for a in (0.7, 1.0, 1.5) for b in (0.8, 1.3, 2.0)])
+    thetas[:, -1] = [0.0, 0.05, 0.0, 0.1, 0.0, 0.0, 0.2, 0.0, 0.0]
+    lml, sweeps, info = ctx.ep_lml_rbf_batched(p["X"], y, thetas, stop_eps=0.01, max_sweeps=40, strict=strict)
+    assert np.all(info == 0)
+    for b in range(thetas.shape[0]):
+        K = orc.gram_sym(p["X"], thetas[b])
+        o = orc.ep_estimate(K, y, 40, eps=0.01)
+        assert sweeps[b] == o["sweeps"], b
+        ol = orc.ep_lml(o, y, strict)
+        assert abs(lml[b] - ol) <= 1e-8 * abs(ol), b
+    # fixed sweep count (stop_eps < 0) and a single setting give the same numbers as the per-object API
+    l3, s3, _ = ctx.ep_lml_rbf_batched(p["X"], y, thetas[4:5], stop_eps=-1.0, max_sweeps=3, strict=strict)
+    from gp_algos_amd.core import EpClassifierState
+    st = EpClassifierState(ctx, orc.gram_sym(p["X"], thetas[4]), y)
+    st.sweep(3)
+    assert s3[0] == 3 and abs(l3[0] - st.lml(strict=strict)) <= 1e-12 * abs(l3[0])
+    st.close()
+
+
+def test_ep_lml_batched_errors_and_mesh_mirror(ctx):
+    from gp_algos_amd import set_default_context
+    from gp_algos_amd.gp.classification.ep_parameter_estimator import AvgBasedStopCriterion
+    from gp_algos_amd.gp.classification.marginal_likelihood_evaluator import (MarginalLikelihoodEvaluator,
+                                                                             MeshHyperParamsLogLikelihoodEvaluator)
+    from gp_algos_amd.utils.kernel_requisites import GaussianRbfKernel, GaussianRbfParams
+    set_default_context(ctx)
+    p, _, y = _ep_problem(90, seed=8)
+    with pytest.raises(ValueError):
+        ctx.ep_lml_rbf_batched(p["X"], np.where(np.arange(90) == 5, 0, y), p["theta"][None, :])   # labels outside {-1, 1}
+    with pytest.raises(ValueError):
+        ctx.ep_lml_rbf_batched(p["X"], y, p["theta"][None, :-1])
+    empty = ctx.ep_lml_rbf_batched(p["X"], y, np.zeros((0, 5)))
+    assert empty[0].shape == (0,)
+    kf = GaussianRbfKernel(GaussianRbfParams(1.0, [1.0, 1.0, 1.0], 0.0))
+    ev = MarginalLikelihoodEvaluator(AvgBasedStopCriterion(0.01), kf, strict=True)
+    settings, vals = MeshHyperParamsLogLikelihoodEvaluator(ev).evaluate([[1.0, 1.6], [1.1], [1.1], [0.9, 1.3], [0.0]], p["X"], y)
+    assert len(settings) == 4
+    for th, v in zip(settings, vals):          # the batched grid equals the one-setting-at-a-time mirror path
+        one = ev.logLikelihoodWithoutGrad(p["X"], y, th)
+        assert abs(v - one) <= 1e-9 * abs(one)
+
+
 # ---- edge cases: empty / ragged / maximum feature count / strided views ---------------------------
 def test_empty_inputs(ctx):
     K = ctx.gram_rbf(np.zeros((0, 3)), [1.0, 1.0, 1.0, 1.0, 0.1])
