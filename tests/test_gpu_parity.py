@@ -513,6 +513,22 @@ def test_ill_conditioned_but_pd_problem(ctx):
     mdl.close()
 
 
+def test_predict_many_points_small_model(ctx):
+    """m large enough for the folded (Lw) posterior path at its default threshold, n small and not a multiple of 128."""
+    from gp_algos_amd.core import RegressionModel
+    p = _problem(100, 3, 24700, seed=77)
+    mdl = RegressionModel(ctx, p["X"], p["y"], p["theta"])
+    mean, var, _ = mdl.predict(p["Xs"])
+    Lo, ao = orc.fit(p["X"], p["y"], p["theta"])
+    omean, ovar, _, _ = orc.predict(p["X"], p["theta"], Lo, ao, p["Xs"])
+    assert np.max(np.abs(mean - omean)) <= TOL_MEAN * max(1.0, np.max(np.abs(omean)))
+    assert np.max(np.abs(var - ovar)) <= TOL_VAR * p["theta"][0] ** 2
+    mean2, var2, _ = mdl.predict(p["Xs"][:500])          # small batch after a large one: right-looking form, same model
+    assert np.max(np.abs(mean2 - omean[:500])) <= TOL_MEAN * max(1.0, np.max(np.abs(omean)))
+    assert np.max(np.abs(var2 - ovar[:500])) <= TOL_VAR * p["theta"][0] ** 2
+    mdl.close()
+
+
 _LEFT_LOOKING_CHILD = r"""
 import sys, numpy as np
 sys.path.insert(0, sys.argv[1])
