@@ -47,8 +47,20 @@ struct gp_ep {
     double *tmp2() { return vec + 9 * (size_t)np; }
 };
 
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
 namespace {
 
+// 1/x to within an ulp or two: v_rcp_f64 + two Newton steps (the body of the IEEE division sequence without its scaling
+// and fix-up instructions; operands here are O(1) variances and precisions, never denormal).  Only used on the serial
+// per-site chain of ep_block_kernel, where every dependent instruction is paid 128 times per block.
+__device__ __forceinline__ double rcp_nr(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-x, r, 1.0);
+    return fma(r, e, r);
+}
 __device__ __forceinline__ double dnorm_d(double x) { return exp(-(x * x) / 2.0 - log(sqrt(2.0 * M_PI))); }   // StatsUtils.scala:15
 __device__ __forceinline__ double pnorm_d(double x) { return 0.5 * (1.0 + erf(x / sqrt(2.0))); }              // StatsUtils.scala:17
 
@@ -94,36 +106,48 @@ __global__ __launch_bounds__(192) void ep_block_kernel(int n, int np, int i0, in
         yb[r] = live ? (double)y[i0 + r] : 0.0;
     }
     __syncthreads();
-    // Software pipeline over the sites of the block.  At the top of iteration t column t already holds s_t and mb is
-    // current through site t-1.  While ONE lane of wave 2 runs the scalar site update t (the serial chain: erf, exp,
-    // reciprocals), waves 0-1 build every term of s_{t+1} that does not depend on it (q < t); after the barrier they add
-    // the q = t term, update mu, and publish column t+1.
+    // Only entries on or below the diagonal of the block are ever used (s_t[r] matters for r >= t: the mean of the sites still
+    // to come, the unit-lower factor Lmat, and the later columns' own lower parts), and only the lower triangle of Sigma0 is
+    // kept current during a sweep (see gp_ep_sweep); the strict upper triangle of A is dead storage.
+    //
+    // Sites are processed in chunks of 16.  Within a chunk the pipeline is as before: while ONE lane of wave 2 runs the scalar
+    // site update t (the serial chain: erf, exp, reciprocals), waves 0-1 build the terms of s_{t+1} that come from the chunk's
+    // earlier sites (q < t, at most 14 of them); after the barrier they add the q = t term, update mu, and publish column
+    // t+1.  At a chunk boundary the 16 finished columns are applied to ALL later columns at once on the matrix cores
+    //   A[I-tile, J-tile] -= (S[I-tile, chunk] diag(c)) S[J-tile, chunk]^T     for chunk < J <= I
+    // so a site never walks over more than one chunk of history (the former O(t) loop over all earlier sites was the
+    // longest thing in an iteration: 128^2/2 dependent LDS round trips per block).
+    const int lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
+    const int jtiles = (bsz + 15) >> 4;
     for (int t = 0; t < bsz; ++t) {
+        const int cs0 = t & ~15;
+        const bool boundary = ((t + 1) & 15) == 0;          // site t closes its chunk
+        const bool next_col = (t + 1 < bsz) && !boundary;   // column t+1 is completed by this iteration's row threads
         double part = 0.0;
         if (!rowthread) {
             if (tid == GP_NB) {
                 // Site update, EpParameterEstimator.scala:45-53 + marginalMoments :98-109, with the divisions folded:
-                // the reference's 12 divisions and 2 square roots become 4 reciprocals and one rsqrt.  Same formulas,
+                // the reference's 12 divisions and 2 square roots become 5 Newton reciprocals and one rsqrt.  Same formulas,
                 // re-associated; fp64 throughout.
                 const int i = i0 + t;
                 const double sii = Sb[t + t * LS], mui = mb[t];
                 const double to = tb[t], no = nb[t];
-                const double rs = 1.0 / sii;
+                const double rs = rcp_nr(sii);
                 const double tc = rs - to;                              // cavity tau  :45
                 const double nc = mui * rs - no;                        // cavity nu   :46
-                const double cvr = 1.0 / tc;                            // cavity variance 1/tau
+                const double cvr = rcp_nr(tc);                          // cavity variance 1/tau
                 const double cm = nc * cvr;                             // cavity mean
                 const double yi = yb[t];
                 const double rt = rsqrt(1.0 + cvr);                     // 1/sqrt(1 + sigma^2)
                 const double z = (yi * cm) * rt;
-                const double ratio = dnorm_d(z) / pnorm_d(z);           // phi(z)/Phi(z)
+                const double ratio = dnorm_d(z) * rcp_nr(pnorm_d(z));    // phi(z)/Phi(z)
                 const double mi_hat = cm + (yi * cvr) * (ratio * rt);
                 const double sg_hat = cvr - (cvr * cvr) * (ratio * (z + ratio)) * (rt * rt);
-                const double isg = 1.0 / sg_hat;
+                const double isg = rcp_nr(sg_hat);
                 const double dtau = isg - tc - to;                      // :49
                 const double tn = to + dtau;                            // :50
                 const double nn = mi_hat * isg - nc;                    // :51
-                const double c = dtau / fma(dtau, sii, 1.0);            // 1/(1/dtau + sii), finite at dtau = 0  :53
+                const double c = dtau * rcp_nr(fma(dtau, sii, 1.0));     // 1/(1/dtau + sii), finite at dtau = 0  :53
                 const double dnu = nn - no;
                 const double coef = dnu - c * (mui + dnu * sii);
                 sc[0] = coef;
@@ -132,12 +156,12 @@ __global__ __launch_bounds__(192) void ep_block_kernel(int n, int np, int i0, in
                 cvec[t] = c;
                 ncoef[t] = -coef;
             }
-        } else if (t + 1 < bsz) {
+        } else if (next_col && r > t) {
             double p0 = A[r + (t + 1) * LS], p1 = 0.0, p2 = 0.0, p3 = 0.0;
-            int q = 0;
+            int q = cs0;
             for (; q + 8 <= t; q += 8) {
                 // all 24 LDS reads of the group first, then the arithmetic: left alone the scheduler sometimes interleaves
-                // read / wait / fma one pair at a time, which doubles the time of this loop (the longest thing in an iteration)
+                // read / wait / fma one pair at a time
                 double cq[8], sq[8], sr[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
@@ -166,12 +190,35 @@ __global__ __launch_bounds__(192) void ep_block_kernel(int n, int np, int i0, in
             part = (p0 + p1) + (p2 + p3);
         }
         __syncthreads();
-        if (rowthread) {
+        if (rowthread && r > t) {
             const double st = Sb[r + t * LS];
-            const double wt = cs[t] * Sb[(t + 1 < GP_NB ? t + 1 : t) + t * LS];   // c_t * S[i_{t+1}, t]
             mb[r] = fma(st, sc[0], mb[r]);
-            // column t+1 of the Sigma0 block was only ever read by its own row thread (above), so it can be replaced now
-            if (t + 1 < bsz) Sb[r + (t + 1) * LS] = fma(-wt, st, part);
+            if (next_col) {
+                const double wt = cs[t] * Sb[(t + 1) + t * LS];   // c_t * S[i_{t+1}, t]
+                Sb[r + (t + 1) * LS] = fma(-wt, st, part);
+            }
+        }
+        if (boundary && t + 1 < bsz) {
+            // chunk update on the matrix cores, all three waves; tiles (I, J), jc <= J <= I < 8, J < jtiles
+            const int jc = (t + 1) >> 4;
+            int q = wave;
+            for (int J = jc; J < jtiles; ++J)
+                for (int I = J; I < 8; ++I, q = (q == 0 ? 2 : q - 1)) {
+                    if (q != 0) continue;
+                    const int ri = 16 * I, rj = 16 * J;
+                    double4_t acc;
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) acc[rr] = A[(ri + fr) + (rj + fg + 4 * rr) * LS];
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        const int qq = cs0 + 4 * ks + fg;
+                        const double aop = -(cs[qq] * Sb[(rj + fr) + qq * LS]);
+                        const double bop = Sb[(ri + fr) + qq * LS];
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, acc, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) A[(ri + fr) + (rj + fg + 4 * rr) * LS] = acc[rr];
+                }
         }
         __syncthreads();
     }
@@ -378,16 +425,23 @@ gp_status gp_ep_sweep(gp_ep *ep, int nsweeps, double *tau, double *nu, int *info
             double *ncoef = ep->cvec + GP_NB;
             hipLaunchKernelGGL(ep_block_kernel, dim3(1), dim3(192), EP_BLOCK_LDS, s, n, np, i0, bsz, ep->Sig, ep->mu(), ep->y,
                                ep->tau(), ep->nu(), ep->cav_tau(), ep->cav_nu(), ep->cvec, ncoef, Lmat);
-            // full-height delayed columns S = Sigma0[:, blk] Lmat^-T, then mu += S coef for every row
-            gpk_copy_2d(s, ep->S, np, ep->Sig + (size_t)i0 * np, np, np, GP_NB);
-            gpk_tile_inverses(s, Lmat, GP_NB, GP_NB, bdinv);
-            gpk_trsm_panel128(s, ep->S, np, np, Lmat, GP_NB, bdinv, nullptr);
-            gpk_gemv_panel_sub(s, ep->S, n, np, ncoef, ep->mu());
-            if (i0 + bsz < n) {   // the last block's update would only feed a Sigma that the refactorisation discards (:60)
-                hipLaunchKernelGGL(scale_cols_kernel, dim3(512), dim3(256), 0, s, ep->Sc, ep->S, ep->cvec, np, GP_NB, np);
+            // Only the TRAILING part of the recurrence is carried: the sites after this block read mu_i and Sigma_ii "as of
+            // now", which depend on the earlier blocks through rows/columns >= their own block only, and the end-of-sweep
+            // refactorisation (:56-61) rebuilds Sigma and mu from the site parameters anyway.  So the delayed columns
+            // S = Sigma0[r0:, blk] Lmat^-T, the mean update mu[r0:] += S coef and the rank-128 update
+            // Sigma[r0:, r0:] -= S diag(c) S^T cover rows/columns r0 = i0 + 128 onwards (lower triangle: the block kernel mirrors
+            // its diagonal block on load) -- n^3/3 flops per sweep on the MFMA syrk instead of 2 n^3 on full-square updates.
+            const int r0 = i0 + GP_NB, rt = np - r0;
+            if (rt > 0 && r0 < n) {
+                double *St = ep->S + r0, *Sct = ep->Sc + r0;
+                gpk_copy_2d(s, St, np, ep->Sig + (size_t)r0 + (size_t)i0 * np, np, rt, GP_NB);
+                gpk_tile_inverses(s, Lmat, GP_NB, GP_NB, bdinv);
+                gpk_trsm_panel128(s, St, rt, np, Lmat, GP_NB, bdinv, nullptr);
+                gpk_gemv_panel_sub(s, St, n - r0, np, ncoef, ep->mu() + r0);
+                hipLaunchKernelGGL(scale_cols_kernel, dim3(512), dim3(256), 0, s, Sct, St, ep->cvec, rt, GP_NB, np);
                 gp_prof_begin(ctx, GP_PROF_GEMM);
-                gpk_gemm_nt(s, np, np, GP_NB, -1.0, ep->Sc, np, ep->S, np, 1.0, ep->Sig, np, 0);
-                gp_prof_end(ctx, GP_PROF_GEMM, 2.0 * np * (double)np * GP_NB);
+                gpk_gemm_nt(s, rt, rt, GP_NB, -1.0, Sct, np, St, np, 1.0, ep->Sig + (size_t)r0 + (size_t)r0 * np, np, 1);
+                gp_prof_end(ctx, GP_PROF_GEMM, (double)rt * ((double)rt + GP_NB) * GP_NB);
             }
         }
         GP_TRY(ep_refactor(ep));
