@@ -36,6 +36,7 @@ SIGNATURES = {
     "gp_dev_download": (_i, [_vp, _vp, _vp, _sz]),
     "gp_hp_get_at_position": (_i, [_dp, _i, _i, _dp]),
     "gp_gram_rbf": (_i, [_vp, _dp, _i, _i, _i, _dp, _dp, _i, _i]),
+    "gp_dgram_rbf": (_i, [_vp, _dp, _i, _i, _i, _dp, _i, _dp, _i]),
     "gp_gram_rbf_dev": (_i, [_vp, _vp, _i, _i, _i, _dp, _vp, _i, _i]),
     "gp_cross_gram_rbf": (_i, [_vp, _dp, _i, _i, _dp, _i, _i, _i, _dp, _dp, _i]),
     "gp_potrf_lower": (_i, [_vp, _dp, _i, _i, _ip]),

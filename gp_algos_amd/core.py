@@ -94,6 +94,17 @@ class Context:
                                          L.GP_FULL if full else L.GP_LOWER))
         return K
 
+    def dgram_rbf(self, X, theta, pos):
+        """dK/dtheta_pos (pos 1-based), full symmetric."""
+        X = L.f64(X)
+        n, d = X.shape
+        theta = np.ascontiguousarray(theta, dtype=np.float64)
+        if theta.size != d + 2:
+            raise ValueError("requirement failed: hyper-parameter vector must have d + 2 entries")
+        D = np.zeros((n, n), order="F")
+        self.check(self._lib.gp_dgram_rbf(self.h, L.dptr(X), n, d, max(n, 1), L.dptr(theta), int(pos), L.dptr(D), max(n, 1)))
+        return D
+
     def cross_gram_rbf(self, Xs, X, theta):
         Xs, X, theta = L.f64(Xs), L.f64(X), L.f64(theta)
         m, d = Xs.shape

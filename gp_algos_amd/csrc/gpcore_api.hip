@@ -548,6 +548,23 @@ gp_status gp_gram_rbf(gp_ctx *ctx, const double *X, int n, int d, int ldx, const
     return download_2d(ctx, K, ldk, dK, n, n, n);
 }
 
+gp_status gp_dgram_rbf(gp_ctx *ctx, const double *X, int n, int d, int ldx, const double *theta, int pos, double *D, int ldd) {
+    if (!ctx) return GP_EINVAL;
+    GP_REQUIRE(ctx, X && theta && D, "null pointer");
+    GP_REQUIRE(ctx, n >= 0 && d >= 1 && d <= 64 && ldx >= n && ldd >= n, "bad dimensions (1 <= d <= 64)");
+    if (pos < 1 || pos > d + 2) { GP_SET_ERR(ctx, "hyper-parameter position %d outside 1..%d", pos, d + 2); return GP_ERANGE; }   // MatchError
+    if (n == 0) return GP_OK;
+    GP_HIP(ctx, hipSetDevice(ctx->device));
+    double *dX, *dD;
+    GP_TRY(ws_get(ctx, WS_A, sizeof(double) * (size_t)n * d, &dX));
+    GP_TRY(ws_get(ctx, WS_B, sizeof(double) * (size_t)n * n, &dD));
+    GP_TRY(upload_2d(ctx, dX, n, X, ldx, n, d));
+    gp_prof_begin(ctx, GP_PROF_GRAM);
+    gpk_dgram_sym(ctx->stream, dX, n, d, n, theta, pos, dD, n);
+    gp_prof_end(ctx, GP_PROF_GRAM, 8.0 * n * (double)n + 8.0 * n * d);
+    return download_2d(ctx, D, ldd, dD, n, n, n);
+}
+
 gp_status gp_cross_gram_rbf(gp_ctx *ctx, const double *Xs, int m, int ldxs, const double *X, int n, int ldx, int d, const double *theta, double *Ks, int ldks) {
     if (!ctx) return GP_EINVAL;
     GP_REQUIRE(ctx, Xs && X && theta && Ks, "null pointer");

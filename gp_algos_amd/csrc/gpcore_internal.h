@@ -90,6 +90,7 @@ void gpk_gemm_nt_rowred(hipStream_t s, int M, int N, int K, const double *A, int
                         double *sumsq, const double *tvec, double *dots);
 // ARD-RBF Gram.  theta on host.  symmetric: Xb == Xa, noise on the diagonal, tiles bi >= bj only (mirrored if full).
 void gpk_gram_sym(hipStream_t s, const double *X, int n, int d, int ldx, const double *theta, double *K, int ldk, int full, double extra_diag);
+void gpk_dgram_sym(hipStream_t s, const double *X, int n, int d, int ldx, const double *theta, int pos, double *D, int ldd);
 void gpk_gram_cross(hipStream_t s, const double *Xs, int m, int ldxs, const double *X, int n, int ldx, int d, const double *theta, double *Ks, int ldks);
 // set rows/cols [n, np) of the np x np matrix to identity (pad block) and zero the cross blocks.
 void gpk_pad_identity(hipStream_t s, double *A, int n, int np, int lda);

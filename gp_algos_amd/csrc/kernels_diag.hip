@@ -69,9 +69,12 @@ __global__ __launch_bounds__(256) void potrf_diag128_kernel(double *__restrict__
     const int fr = lane & 15, fg = lane >> 4;
     if (tid == 0) *flag = 0;
     load_block_lds<PLS, true>(a, A, lda, tid);
+    __syncthreads();
+    // Two barriers per micro-panel.  Wave 0 owns the serial part (tile Cholesky + tile inverse, ~3 us) and, of the update that
+    // follows a panel, only the ONE tile it needs next (the following diagonal tile); the other 3 waves apply the rest of that
+    // update while wave 0 is already factoring -- everybody meets again at the barrier after the factorisation.
     for (int jb = 0; jb < NB / 16; ++jb) {
         const int c0 = jb * 16;
-        __syncthreads();
         if (wave == 0) {
             // ---- 16x16 tile: Cholesky (row owner = lane&15) then inverse (column owner = lane&15) ----
             double row[16], invd[16], x[16];
@@ -138,7 +141,7 @@ __global__ __launch_bounds__(256) void potrf_diag128_kernel(double *__restrict__
         __syncthreads();
         // ---- rest of the block:  A(ti,tj) -= P_ti P_tj^T  for jb < tj <= ti ----
         const int ntile = T * (T + 1) / 2;
-        for (int q = wave; q < ntile; q += 4) {
+        for (int q = (wave == 0 ? 0 : wave); q < (wave == 0 ? (ntile > 0 ? 1 : 0) : ntile); q += 3) {
             int bi = 0;
             while ((bi + 1) * (bi + 2) / 2 <= q) ++bi;
             const int bj = q - bi * (bi + 1) / 2;

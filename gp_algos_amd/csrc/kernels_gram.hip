@@ -19,6 +19,10 @@ constexpr int GP_DMAX = 64;
 struct GramParams {
     double sf2, sn2, extra;
     double inv_ls2[GP_DMAX];
+    // derivative mode (GaussianRbfKernel.derAfterHyperParam, KernelRequisites.scala:76-86): 0 = the kernel itself,
+    // 1 = d/d sf (2 sf e), 2 = d/d l_k (sf^2 e (x_k - y_k)^2 l_k^-3, k = dk), 3 = d/d sn (same ? 2 sn : 0)
+    int dmode, dk;
+    double dcoef;   // 2 sf | sf^2 l_k^-3 | 2 sn
 };
 
 __device__ __forceinline__ void tile_lower(int t, int &bi, int &bj) {
@@ -77,6 +81,14 @@ __global__ __launch_bounds__(256) void gram_rbf_kernel(const double *__restrict_
         const int jj = tq + 4 * q, gj = bj * GT + jj;
         double v = prm.sf2 * exp(-0.5 * acc[q]);
         if (SYM && gi == gj) v = (prm.sf2 + prm.sn2) + prm.extra;  // exp(-0) == 1: sf*sf*1 + sn*sn (+ sigmaNoise)
+        if (prm.dmode) {
+            const double e = exp(-0.5 * acc[q]);
+            if (prm.dmode == 1) v = prm.dcoef * e;
+            else if (prm.dmode == 2) {
+                const double diff = (gi < nr && gj < nc) ? Xr[gi + (size_t)prm.dk * ldxr] - Xc[gj + (size_t)prm.dk * ldxc] : 0.0;
+                v = (prm.dcoef * e) * (diff * diff);
+            } else v = (SYM && gi == gj) ? prm.dcoef : 0.0;
+        }
         if (gi < nr && gj < nc && !(diag_tile && !full && gi < gj)) K[gi + (size_t)gj * ldk] = v;
         if (SYM) tile[ti * (GT + 1) + jj] = v;
     }
@@ -132,6 +144,7 @@ GramParams make_params(const double *theta, int d, double extra) {
     p.sf2 = theta[0] * theta[0];
     p.sn2 = theta[d + 1] * theta[d + 1];
     p.extra = extra;
+    p.dmode = 0, p.dk = 0, p.dcoef = 0.0;
     for (int k = 0; k < GP_DMAX; ++k) p.inv_ls2[k] = 0.0;
     for (int k = 0; k < d; ++k) p.inv_ls2[k] = 1.0 / (theta[1 + k] * theta[1 + k]);
     return p;
@@ -143,6 +156,16 @@ void gpk_gram_sym(hipStream_t s, const double *X, int n, int d, int ldx, const d
     GramParams p = make_params(theta, d, extra_diag);
     int nb = (n + GT - 1) / GT;
     hipLaunchKernelGGL(gram_rbf_kernel<true>, dim3(nb * (nb + 1) / 2), dim3(256), 0, s, X, n, ldx, X, n, ldx, d, p, K, ldk, full, nb);
+}
+
+// d K / d theta_pos (pos 1-based, vector order sf, l_1..l_d, sn), full symmetric
+void gpk_dgram_sym(hipStream_t s, const double *X, int n, int d, int ldx, const double *theta, int pos, double *D, int ldd) {
+    GramParams p = make_params(theta, d, 0.0);
+    if (pos == 1) { p.dmode = 1; p.dcoef = 2.0 * theta[0]; }
+    else if (pos < d + 2) { p.dmode = 2; p.dk = pos - 2; p.dcoef = (theta[0] * theta[0]) / (theta[pos - 1] * theta[pos - 1] * theta[pos - 1]); }
+    else { p.dmode = 3; p.dcoef = 2.0 * theta[d + 1]; }
+    int nb = (n + GT - 1) / GT;
+    hipLaunchKernelGGL(gram_rbf_kernel<true>, dim3(nb * (nb + 1) / 2), dim3(256), 0, s, X, n, ldx, X, n, ldx, d, p, D, ldd, 1, nb);
 }
 
 void gpk_gram_cross(hipStream_t s, const double *Xs, int m, int ldxs, const double *X, int n, int ldx, int d, const double *theta, double *Ks, int ldks) {

@@ -36,6 +36,10 @@ def buildMatrixWithFunc(*args):
         data = _mat(args[0])
 
         def build(f):
+            tag = getattr(f, "_gpcore_rbf", None)
+            if tag is not None:      # f = GaussianRbfKernel.derAfterHyperParam(p): gp_dgram_rbf builds dK/dtheta_p on the device
+                kernel, pos = tag
+                return default_context().dgram_rbf(data, kernel.rbfParams.toDenseVector(), pos)
             n = data.shape[0]
             out = np.zeros((n, n), order="F")
             for i in range(n):

@@ -82,6 +82,12 @@ enum { GP_LOWER = 0, GP_FULL = 1 };
  * triangle untouched. */
 gp_status gp_gram_rbf(gp_ctx *ctx, const double *X, int n, int d, int ldx, const double *theta, double *K, int ldk, int uplo);
 gp_status gp_gram_rbf_dev(gp_ctx *ctx, const double *dX, int n, int d, int ldx, const double *theta, double *dK, int ldk, int uplo);
+/* Derivative Gram matrix dK/dtheta_pos, full symmetric, pos 1-BASED in the vector order sf, l_1..l_d, sn:
+ * MatrixUtils.buildMatrixWithFunc(X)(kernel.derAfterHyperParam(pos)), utils/MatrixUtils.scala:72-84 with
+ * GaussianRbfKernel.derAfterHyperParam, utils/KernelRequisites.scala:76-86 (2 sf e | sf^2 e (x_k-y_k)^2 l_k^-3 | i==j ? 2 sn : 0).
+ * The fused gradient entry points never materialise these; this is the reference's building block itself.  pos outside
+ * 1..d+2 -> GP_ERANGE (MatchError). */
+gp_status gp_dgram_rbf(gp_ctx *ctx, const double *X, int n, int d, int ldx, const double *theta, int pos, double *D, int ldd);
 /* MatrixUtils.buildKernelMatrix(kernel, X*, X)  utils/MatrixUtils.scala:44-55,86-97 (never adds
  * noise).  Ks is m x n. */
 gp_status gp_cross_gram_rbf(gp_ctx *ctx, const double *Xs, int m, int ldxs, const double *X, int n, int ldx, int d, const double *theta, double *Ks, int ldks);

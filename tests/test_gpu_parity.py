@@ -78,6 +78,22 @@ def test_cross_gram_vs_oracle(ctx, m, n, d):
     assert np.max(np.abs(Ks - Kso) / np.abs(Kso)) <= TOL_GRAM
 
 
+@pytest.mark.parametrize("n,d", [(5, 1), (130, 3), (200, 9)])
+def test_derivative_gram_vs_oracle(ctx, n, d):   # derAfterHyperParam, KernelRequisites.scala:76-86, through buildMatrixWithFunc
+    p = _problem(n, d, 0, seed=n + 2 * d)
+    for pos in range(1, d + 3):
+        D = ctx.dgram_rbf(p["X"], p["theta"], pos)
+        Do = orc.dgram_sym(p["X"], p["theta"], pos)
+        assert np.array_equal(D, D.T)
+        assert np.max(np.abs(D - Do)) <= 1e-13 * max(1.0, np.max(np.abs(Do))), pos
+        if pos == d + 2:                                   # i == j ? 2 sn : 0, exactly
+            assert np.array_equal(D, 2.0 * p["theta"][-1] * np.eye(n))
+    with pytest.raises(IndexError):                        # MatchError past the last position
+        ctx.dgram_rbf(p["X"], p["theta"], d + 3)
+    with pytest.raises(IndexError):
+        ctx.dgram_rbf(p["X"], p["theta"], 0)
+
+
 def test_gram_argument_errors(ctx):
     with pytest.raises(ValueError):      # fromDenseVector require, KernelRequisites.scala:55
         ctx.gram_rbf(np.zeros((4, 2)), [1.0, 1.0, 0.1])

@@ -207,3 +207,20 @@ def test_ep_classifier_on_the_reference_cancer_data():
     assert np.max(np.abs(probs - oprob)) <= 1e-8
     acc = np.mean((probs > 0.5) == (y[ntr:] == 1))
     assert acc > 0.93
+
+
+def test_derivative_matrices_like_logLikelihoodWithDerivatives_builds_them():
+    """GpPredictor.scala:70-78 builds dK/dtheta_p with MatrixUtils.buildMatrixWithFunc(X)(kernel.derAfterHyperParam(p)); the
+    mirror keeps that call shape and the matrix comes from gp_dgram_rbf.  Host closure (the Scala formulas) = device matrix."""
+    from gp_algos_amd.utils import matrix_utils as MU
+    from gp_algos_amd.utils.kernel_requisites import GaussianRbfKernel, GaussianRbfParams, MatchError
+    rng = np.random.default_rng(4)
+    X = np.asfortranarray(rng.normal(size=(40, 3)))
+    kf = GaussianRbfKernel(GaussianRbfParams(1.4, np.array([0.9, 1.7, 1.1]), 0.3))
+    for p in range(1, kf.hyperParametersNum + 1):
+        f = kf.derAfterHyperParam(p)
+        D = MU.buildMatrixWithFunc(X)(f)
+        host = np.array([[f(X[i], X[j], i == j) for j in range(40)] for i in range(40)])
+        assert np.max(np.abs(D - host)) <= 1e-13 * max(1.0, np.max(np.abs(host)))
+    with pytest.raises(MatchError):
+        kf.derAfterHyperParam(6)(X[0], X[1], False)
