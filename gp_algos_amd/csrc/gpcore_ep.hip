@@ -154,7 +154,7 @@ __global__ __launch_bounds__(192) void ep_block_kernel(int n, int np, int i0, in
                 cs[t] = c;
                 tau[i] = tn; nu[i] = nn; cav_tau[i] = tc; cav_nu[i] = nc;
                 cvec[t] = c;
-                ncoef[t] = -coef;
+                ncoef[t] = coef;
             }
         } else if (next_col && r > t) {
             double p0 = A[r + (t + 1) * LS], p1 = 0.0, p2 = 0.0, p3 = 0.0;
@@ -422,7 +422,7 @@ gp_status gp_ep_sweep(gp_ep *ep, int nsweeps, double *tau, double *nu, int *info
         for (int i0 = 0; i0 < n; i0 += GP_NB) {
             const int bsz = (n - i0 < GP_NB) ? n - i0 : GP_NB;
             double *Lmat = ep->blk, *bdinv = ep->blk + GP_NB * GP_NB;
-            double *ncoef = ep->cvec + GP_NB;
+            double *ncoef = ep->cvec + GP_NB;   // + coef of every site of the block
             hipLaunchKernelGGL(ep_block_kernel, dim3(1), dim3(192), EP_BLOCK_LDS, s, n, np, i0, bsz, ep->Sig, ep->mu(), ep->y,
                                ep->tau(), ep->nu(), ep->cav_tau(), ep->cav_nu(), ep->cvec, ncoef, Lmat);
             // Only the TRAILING part of the recurrence is carried: the sites after this block read mu_i and Sigma_ii "as of
@@ -433,12 +433,11 @@ gp_status gp_ep_sweep(gp_ep *ep, int nsweeps, double *tau, double *nu, int *info
             // its diagonal block on load) -- n^3/3 flops per sweep on the MFMA syrk instead of 2 n^3 on full-square updates.
             const int r0 = i0 + GP_NB, rt = np - r0;
             if (rt > 0 && r0 < n) {
-                double *St = ep->S + r0, *Sct = ep->Sc + r0;
-                gpk_copy_2d(s, St, np, ep->Sig + (size_t)r0 + (size_t)i0 * np, np, rt, GP_NB);
+                // the block's own column panel of Sigma is dead after this block, so it is solved in place; the same launch
+                // writes the scaled copy S diag(c) and adds S coef to the mean (row dot fused into the panel solve)
+                double *St = ep->Sig + (size_t)r0 + (size_t)i0 * np, *Sct = ep->Sc + r0;
                 gpk_tile_inverses(s, Lmat, GP_NB, GP_NB, bdinv);
-                gpk_trsm_panel128(s, St, rt, np, Lmat, GP_NB, bdinv, nullptr);
-                gpk_gemv_panel_sub(s, St, n - r0, np, ncoef, ep->mu() + r0);
-                hipLaunchKernelGGL(scale_cols_kernel, dim3(512), dim3(256), 0, s, Sct, St, ep->cvec, rt, GP_NB, np);
+                gpk_trsm_panel128(s, St, rt, np, Lmat, GP_NB, bdinv, nullptr, ncoef, ep->mu() + r0, gp_batch(), Sct, ep->cvec);
                 gp_prof_begin(ctx, GP_PROF_GEMM);
                 gpk_gemm_nt(s, rt, rt, GP_NB, -1.0, Sct, np, St, np, 1.0, ep->Sig + (size_t)r0 + (size_t)r0 * np, np, 1);
                 gp_prof_end(ctx, GP_PROF_GEMM, (double)rt * ((double)rt + GP_NB) * GP_NB);

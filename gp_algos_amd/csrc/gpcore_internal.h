@@ -123,7 +123,8 @@ int gpk_init_diag_kernels();
 void gpk_potrf_diag128(hipStream_t s, double *A, int lda, double *dinv_k, int *d_info, int base, gp_batch bt = gp_batch());   // strides: A, dinv; d_info + 1 per problem
 // optional fused row reductions: sumsq[p] += sum_c X(p,c)^2 ; dots[p] += sum_c X(p,c) tvec[c]
 void gpk_trsm_panel128(hipStream_t s, double *X, int M, int ldx, const double *Lkk, int ldl, const double *dinv_k, double *sumsq,
-                       const double *tvec = nullptr, double *dots = nullptr, gp_batch bt = gp_batch());   // strides: X, Lkk, dinv (no fused reductions when batched)
+                       const double *tvec = nullptr, double *dots = nullptr, gp_batch bt = gp_batch(),   // strides: X, Lkk, dinv (no fused reductions when batched)
+                       double *X2 = nullptr, const double *cs2 = nullptr);   // optional second output X2(p,c) = X(p,c) * cs2[c] (same ld as X)
 void gpk_fwd_step(hipStream_t s, const double *L, int ldl, const double *dinv_k, double *t, double *sol, int k0, int r);
 void gpk_bwd_step(hipStream_t s, const double *L, int ldl, const double *dinv_k, double *t, double *sol, int k0);
 void gpk_tile_inverses(hipStream_t s, const double *L, int np, int ldl, double *dinv);

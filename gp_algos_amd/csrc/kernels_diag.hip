@@ -209,7 +209,8 @@ __device__ __forceinline__ void trsm_chunk(double *xs, int sp, int fr, int fg, c
 
 __global__ __launch_bounds__(256, 2) void trsm_panel128_kernel(double *__restrict__ X, int ldx, const double *__restrict__ L, int ldl,
                                                              const double *__restrict__ dinv, double *__restrict__ sumsq,
-                                                             const double *__restrict__ tvec, double *__restrict__ dots, gp_batch bt) {
+                                                             const double *__restrict__ tvec, double *__restrict__ dots, gp_batch bt,
+                                                             double *__restrict__ X2, const double *__restrict__ cs2) {
     extern __shared__ __attribute__((aligned(16))) double xs[];   // NB x XS
     if (bt.tri && (int)blockIdx.x * 64 >= ((int)blockIdx.y + 1) * NB) return;   // problem g only has (g+1)*128 non-zero rows
     X += (size_t)blockIdx.y * bt.s0;      // blockIdx.y = problem of a lockstep batch
@@ -253,6 +254,15 @@ __global__ __launch_bounds__(256, 2) void trsm_panel128_kernel(double *__restric
 #pragma unroll
     for (int q = 0; q < 16; ++q)
         *reinterpret_cast<double2_t *>(Xg + li + (size_t)(lc + 8 * q) * ldx) = *reinterpret_cast<const double2_t *>(xs + (lc + 8 * q) * XS + li);
+    if (X2) {   // second copy with column c scaled by cs2[c] (EP: S diag(c), the other operand of the rank-128 update)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            double2_t v = *reinterpret_cast<const double2_t *>(xs + (lc + 8 * q) * XS + li);
+            const double sc = cs2[lc + 8 * q];
+            v.x *= sc, v.y *= sc;
+            *reinterpret_cast<double2_t *>(X2 + row0 + li + (size_t)(lc + 8 * q) * ldx) = v;
+        }
+    }
     if (dots && tid < 64) {   // fused row dot with this block's slice of t = L^-1 y: the posterior mean  V^T (L^-1 y)
         double acc = 0.0;
 #pragma unroll 8
@@ -389,9 +399,9 @@ void gpk_potrf_diag128(hipStream_t s, double *A, int lda, double *dinv, int *d_i
     hipLaunchKernelGGL(potrf_diag128_kernel, dim3(bt.count), dim3(256), POTRF_LDS, s, A, lda, dinv, d_info, base, bt);
 }
 void gpk_trsm_panel128(hipStream_t s, double *X, int M, int ldx, const double *Lkk, int ldl, const double *dinv, double *sumsq,
-                       const double *tvec, double *dots, gp_batch bt) {
+                       const double *tvec, double *dots, gp_batch bt, double *X2, const double *cs2) {
     if (M <= 0 || bt.count <= 0) return;
-    hipLaunchKernelGGL(trsm_panel128_kernel, dim3(M / 64, bt.count), dim3(256), TRSM_LDS, s, X, ldx, Lkk, ldl, dinv, sumsq, tvec, dots, bt);
+    hipLaunchKernelGGL(trsm_panel128_kernel, dim3(M / 64, bt.count), dim3(256), TRSM_LDS, s, X, ldx, Lkk, ldl, dinv, sumsq, tvec, dots, bt, X2, cs2);
 }
 void gpk_fwd_step(hipStream_t s, const double *L, int ldl, const double *dinv_k, double *t, double *sol, int k0, int r) {
     int grid = r > 0 ? (r + 255) / 256 : 1;
