@@ -25,6 +25,7 @@ SIGNATURES = {
     "gp_ctx_create": (_i, [_i, _vp, C.POINTER(_vp)]),
     "gp_ctx_destroy": (None, [_vp]),
     "gp_ctx_sync": (_i, [_vp]),
+    "gp_ctx_trim": (_i, [_vp]),
     "gp_last_error": (C.c_char_p, [_vp]),
     "gp_ctx_profile": (_i, [_vp, _i]),
     "gp_ctx_profile_read": (_i, [_vp, _i, C.POINTER(C.c_int64), _dp, _dp]),

@@ -41,6 +41,10 @@ class Context:
             raise IndexError(msg)
         raise L.GpCoreError(st, msg, info)
 
+    def trim(self):
+        """Release cached device workspaces (gp_ctx_trim)."""
+        self.check(self._lib.gp_ctx_trim(self.h))
+
     def sync(self):
         self.check(self._lib.gp_ctx_sync(self.h))
 

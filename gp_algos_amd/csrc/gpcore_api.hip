@@ -461,6 +461,17 @@ void gp_ctx_destroy(gp_ctx *ctx) {
     delete static_cast<gp_ctx_full *>(ctx);
 }
 
+gp_status gp_ctx_trim(gp_ctx *ctx) {
+    if (!ctx) return GP_EINVAL;
+    GP_HIP(ctx, hipSetDevice(ctx->device));
+    GP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx_ext *x = ext_of(ctx);
+    for (gp_ctx *c : x->children) GP_TRY(gp_ctx_trim(c));
+    for (int i = 0; i < WS_COUNT; ++i)
+        if (x->ws[i].p) { (void)hipFree(x->ws[i].p); x->ws[i].p = nullptr; x->ws[i].bytes = 0; }
+    return GP_OK;
+}
+
 gp_status gp_ctx_sync(gp_ctx *ctx) {
     if (!ctx) return GP_EINVAL;
     GP_HIP(ctx, hipStreamSynchronize(ctx->stream));

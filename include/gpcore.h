@@ -49,6 +49,9 @@ const char *gp_version(void);
 gp_status gp_ctx_create(int device, void *stream, gp_ctx **out);
 void gp_ctx_destroy(gp_ctx *ctx);
 gp_status gp_ctx_sync(gp_ctx *ctx);
+/* Releases the context's cached workspaces (posterior batches, lockstep LML groups, ... can hold tens of GB between calls in a
+ * long-lived process); models and EP states are untouched, the next call that needs a workspace allocates it again. */
+gp_status gp_ctx_trim(gp_ctx *ctx);
 const char *gp_last_error(const gp_ctx *ctx);
 /* Per-kernel timing with HIP events on the context's stream.  `mask` is an OR of (1 << GP_PROF_x);
  * while set, every launch of those kernel classes is bracketed by events.  gp_ctx_profile_read

@@ -459,6 +459,19 @@ def test_ep_lml_batched_errors_and_mesh_mirror(ctx):
         assert abs(v - one) <= 1e-9 * abs(one)
 
 
+def test_ctx_trim_releases_workspaces_and_work_continues(ctx):
+    from gp_algos_amd.core import RegressionModel
+    p = _problem(260, 3, 300, seed=9)
+    mdl = RegressionModel(ctx, p["X"], p["y"], p["theta"])
+    m1, v1, _ = mdl.predict(p["Xs"])
+    l1, g1, _ = ctx.lml_grad_batched(p["X"], p["y"], np.stack([p["theta"], 1.2 * p["theta"], 0.8 * p["theta"]]))
+    ctx.trim()
+    m2, v2, _ = mdl.predict(p["Xs"])                      # the model survives, workspaces come back on demand
+    l2, g2, _ = ctx.lml_grad_batched(p["X"], p["y"], np.stack([p["theta"], 1.2 * p["theta"], 0.8 * p["theta"]]))
+    assert np.array_equal(m1, m2) and np.array_equal(v1, v2) and np.array_equal(l1, l2) and np.array_equal(g1, g2)
+    mdl.close()
+
+
 # ---- edge cases: empty / ragged / maximum feature count / strided views ---------------------------
 def test_empty_inputs(ctx):
     K = ctx.gram_rbf(np.zeros((0, 3)), [1.0, 1.0, 1.0, 1.0, 0.1])
