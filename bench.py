@@ -54,8 +54,11 @@ def run_secondary(args):
     rank, local_rank, world = gdist.env_rank_world()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
+    # Rehearsal knobs for a 1-GPU box only (never set by the driver): several ranks on one device over gloo.
+    if os.environ.get("GPCORE_BENCH_DEVICE") is not None:
+        local_rank = int(os.environ["GPCORE_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
-    gdist.init("nccl", torch.device("cuda", local_rank))
+    gdist.init(os.environ.get("GPCORE_BENCH_BACKEND", "nccl"), torch.device("cuda", local_rank))
     import __graft_entry__ as entry
     entry.build()
     from gp_algos_amd import _lib as L, synth
