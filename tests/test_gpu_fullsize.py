@@ -83,6 +83,44 @@ def test_c2_posterior_identities_and_spot_check(c2):
     assert np.array_equal(m2[:3], mean) and np.max(np.abs(v2[:3] - var)) <= 1e-13
 
 
+def test_c2_large_batch_path_agrees_with_small_batch_path_and_oracle(c2):
+    """m = 32768 goes through the large-batch posterior (panel solves folded into the GEMMs through Lw, reductions in the GEMM
+    epilogue); the same points in batches of 300 go through the right-looking row-panel solves.  Two different code paths, one
+    answer -- and the oracle's scalar substitution on three of the points."""
+    ctx, mdl, p = c2
+    sf2 = p["theta"][0] ** 2
+    big = synth.config_c2(8192, 8, 32768)["Xs"]
+    mean, var, _ = mdl.predict(big)
+    assert np.all(np.isfinite(mean)) and np.all(var > 0.0) and np.all(var <= sf2 + p["theta"][-1] ** 2 + 1e-9)
+    idx = np.sort(np.random.default_rng(1).choice(32768, size=300, replace=False))
+    m2, v2, _ = mdl.predict(np.asfortranarray(big[idx]))
+    assert np.max(np.abs(mean[idx] - m2)) <= 1e-10 * max(1.0, np.max(np.abs(m2)))
+    assert np.max(np.abs(var[idx] - v2)) <= 1e-10 * sf2
+    om, ov, _, _ = orc.predict(p["X"], p["theta"], mdl.L(), mdl.alpha(), np.asfortranarray(big[idx[:3]]))
+    assert np.max(np.abs(mean[idx[:3]] - om)) <= 1e-9 * max(1.0, np.max(np.abs(om)))
+    assert np.max(np.abs(var[idx[:3]] - ov)) <= 1e-9 * sf2
+
+
+def test_odd_sizes_through_the_padded_large_batch_path():
+    """n = 5000 (padded to 5120), d = 5, m = 25000 (padded to 25088): identities at the training inputs and the two posterior
+    code paths against each other."""
+    from gp_algos_amd.core import Context, RegressionModel
+    p = synth.regression(5000, 5, 25000, 71, 72, 73, synth.ard_theta(5, 1.2, 1.0, 0.15))
+    sf2, sn2 = p["theta"][0] ** 2, p["theta"][-1] ** 2
+    with Context(0) as ctx:
+        mdl = RegressionModel(ctx, p["X"], p["y"], p["theta"])
+        alpha = mdl.alpha()
+        Ka = _kmatvec(p["X"], p["theta"], alpha[:, None])[:, 0]
+        assert np.max(np.abs(Ka - p["y"])) <= 1e-9 * np.max(np.abs(p["y"]))
+        both = np.asfortranarray(np.vstack([p["X"][:1000], p["Xs"][:24000]]))      # 25000 rows: large-batch path
+        mean, var, _ = mdl.predict(both)
+        assert np.max(np.abs(mean[:1000] - (p["y"][:1000] - sn2 * alpha[:1000]))) <= 1e-8     # K* = K - sn^2 I at training inputs
+        m2, v2, _ = mdl.predict(np.asfortranarray(both[900:1300]))                    # small batch: right-looking path
+        assert np.max(np.abs(mean[900:1300] - m2)) <= 1e-10 * max(1.0, np.max(np.abs(m2)))
+        assert np.max(np.abs(var[900:1300] - v2)) <= 1e-10 * sf2
+        mdl.close()
+
+
 def test_c3_sized_lml_gradient_against_finite_differences():
     from gp_algos_amd.core import Context
     p = synth.config_c3(4096, 8)
