@@ -207,6 +207,7 @@ __device__ __forceinline__ void trsm_chunk(double *xs, int sp, int fr, int fg, c
     }
 }
 
+template <bool SCALED_COPY>
 __global__ __launch_bounds__(256, 2) void trsm_panel128_kernel(double *__restrict__ X, int ldx, const double *__restrict__ L, int ldl,
                                                              const double *__restrict__ dinv, double *__restrict__ sumsq,
                                                              const double *__restrict__ tvec, double *__restrict__ dots, gp_batch bt,
@@ -254,8 +255,9 @@ __global__ __launch_bounds__(256, 2) void trsm_panel128_kernel(double *__restric
 #pragma unroll
     for (int q = 0; q < 16; ++q)
         *reinterpret_cast<double2_t *>(Xg + li + (size_t)(lc + 8 * q) * ldx) = *reinterpret_cast<const double2_t *>(xs + (lc + 8 * q) * XS + li);
-    if (X2) {   // second copy with column c scaled by cs2[c] (EP: S diag(c), the other operand of the rank-128 update)
-#pragma unroll
+    if (SCALED_COPY) {   // second copy with column c scaled by cs2[c] (EP: S diag(c), the other operand of the rank-128 update)
+        __builtin_amdgcn_sched_barrier(0);   // keep these loads below the solve: hoisted, they push the kernel into scratch
+#pragma unroll 4
         for (int q = 0; q < 16; ++q) {
             double2_t v = *reinterpret_cast<const double2_t *>(xs + (lc + 8 * q) * XS + li);
             const double sc = cs2[lc + 8 * q];
@@ -388,7 +390,8 @@ static constexpr int STEP_LDS = (NB * LS1 + 8 * 256 + NB + 16) * (int)sizeof(dou
 
 int gpk_init_diag_kernels() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(potrf_diag128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, POTRF_LDS);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(trsm_panel128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, TRSM_LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(trsm_panel128_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, TRSM_LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(trsm_panel128_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, TRSM_LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(fwd_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, STEP_LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(bwd_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, STEP_LDS);
     return e == hipSuccess ? 0 : 1;
@@ -401,7 +404,10 @@ void gpk_potrf_diag128(hipStream_t s, double *A, int lda, double *dinv, int *d_i
 void gpk_trsm_panel128(hipStream_t s, double *X, int M, int ldx, const double *Lkk, int ldl, const double *dinv, double *sumsq,
                        const double *tvec, double *dots, gp_batch bt, double *X2, const double *cs2) {
     if (M <= 0 || bt.count <= 0) return;
-    hipLaunchKernelGGL(trsm_panel128_kernel, dim3(M / 64, bt.count), dim3(256), TRSM_LDS, s, X, ldx, Lkk, ldl, dinv, sumsq, tvec, dots, bt, X2, cs2);
+    if (X2)
+        hipLaunchKernelGGL(trsm_panel128_kernel<true>, dim3(M / 64, bt.count), dim3(256), TRSM_LDS, s, X, ldx, Lkk, ldl, dinv, sumsq, tvec, dots, bt, X2, cs2);
+    else
+        hipLaunchKernelGGL(trsm_panel128_kernel<false>, dim3(M / 64, bt.count), dim3(256), TRSM_LDS, s, X, ldx, Lkk, ldl, dinv, sumsq, tvec, dots, bt, X2, cs2);
 }
 void gpk_fwd_step(hipStream_t s, const double *L, int ldl, const double *dinv_k, double *t, double *sol, int k0, int r) {
     int grid = r > 0 ? (r + 255) / 256 : 1;

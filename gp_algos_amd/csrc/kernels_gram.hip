@@ -33,7 +33,7 @@ __device__ __forceinline__ void tile_lower(int t, int &bi, int &bj) {
     bj = t - b * (b + 1) / 2;
 }
 
-template <bool SYM>
+template <bool SYM, bool DER = false>
 __global__ __launch_bounds__(256) void gram_rbf_kernel(const double *__restrict__ Xr, int nr, int ldxr,
                                                        const double *__restrict__ Xc, int nc, int ldxc, int d,
                                                        GramParams prm, double *__restrict__ K, int ldk, int full,
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void gram_rbf_kernel(const double *__restrict_
         const int jj = tq + 4 * q, gj = bj * GT + jj;
         double v = prm.sf2 * exp(-0.5 * acc[q]);
         if (SYM && gi == gj) v = (prm.sf2 + prm.sn2) + prm.extra;  // exp(-0) == 1: sf*sf*1 + sn*sn (+ sigmaNoise)
-        if (prm.dmode) {
+        if (DER) {   // compile-time: the plain Gram kernels carry none of this
             const double e = exp(-0.5 * acc[q]);
             if (prm.dmode == 1) v = prm.dcoef * e;
             else if (prm.dmode == 2) {
@@ -165,7 +165,7 @@ void gpk_dgram_sym(hipStream_t s, const double *X, int n, int d, int ldx, const 
     else if (pos < d + 2) { p.dmode = 2; p.dk = pos - 2; p.dcoef = (theta[0] * theta[0]) / (theta[pos - 1] * theta[pos - 1] * theta[pos - 1]); }
     else { p.dmode = 3; p.dcoef = 2.0 * theta[d + 1]; }
     int nb = (n + GT - 1) / GT;
-    hipLaunchKernelGGL(gram_rbf_kernel<true>, dim3(nb * (nb + 1) / 2), dim3(256), 0, s, X, n, ldx, X, n, ldx, d, p, D, ldd, 1, nb);
+    hipLaunchKernelGGL((gram_rbf_kernel<true, true>), dim3(nb * (nb + 1) / 2), dim3(256), 0, s, X, n, ldx, X, n, ldx, d, p, D, ldd, 1, nb);
 }
 
 void gpk_gram_cross(hipStream_t s, const double *Xs, int m, int ldxs, const double *X, int n, int ldx, int d, const double *theta, double *Ks, int ldks) {

@@ -12,7 +12,12 @@ dX, dy = ctx.upload(p["X"]), ctx.upload(p["y"])
 theta = L.f64(p["theta"])
 h, info = C.c_void_p(), C.c_int()
 ctx.check(lib.gp_fit_rbf_dev(ctx.h, dX, n, 8, n, dy, L.dptr(theta), float("nan"), C.byref(h), C.byref(info)))
+import time
+ctx.sync()
+t0 = time.perf_counter()
 for _ in range(reps):
     ctx.check(lib.gp_model_refit_dev(h, L.dptr(theta), float("nan")))
 ctx.sync()
+dt = (time.perf_counter() - t0) / reps
+print("n=%d refit %.3f ms -> %.2f TFLOP/s (n^3/3)  GPCORE_OUTER=%s" % (n, dt * 1e3, n ** 3 / 3.0 / dt / 1e12, os.environ.get("GPCORE_OUTER", "default")))
 lib.gp_model_destroy(h)
