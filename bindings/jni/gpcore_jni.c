@@ -49,6 +49,25 @@ JNIEXPORT void JNICALL Java_gpcore_Native_gramRbf(JNIEnv *env, jclass k, jlong h
     if (st != GP_OK) throw_for(env, CTX(h), st, 0);
 }
 
+/* MatrixUtils.buildMatrixWithFunc(X)(kernel.derAfterHyperParam(pos)) -> dK/dtheta_pos (n x n, column-major), pos 1-based */
+JNIEXPORT void JNICALL Java_gpcore_Native_dgramRbf(JNIEnv *env, jclass k, jlong h, jdoubleArray x, jint xoff, jint n, jint d,
+                                                   jint ldx, jdoubleArray theta, jint pos, jdoubleArray out) {
+    double *X = (*env)->GetPrimitiveArrayCritical(env, x, NULL);
+    double *T = (*env)->GetPrimitiveArrayCritical(env, theta, NULL);
+    double *D = (*env)->GetPrimitiveArrayCritical(env, out, NULL);
+    gp_status st = gp_dgram_rbf(CTX(h), X + xoff, n, d, ldx, T, pos, D, n);
+    (*env)->ReleasePrimitiveArrayCritical(env, out, D, 0);
+    (*env)->ReleasePrimitiveArrayCritical(env, theta, T, JNI_ABORT);
+    (*env)->ReleasePrimitiveArrayCritical(env, x, X, JNI_ABORT);
+    if (st != GP_OK) throw_for(env, CTX(h), st, 0);   /* GP_ERANGE -> MatchError */
+}
+
+/* releases the context's cached device workspaces (call between phases of a long-lived JVM) */
+JNIEXPORT void JNICALL Java_gpcore_Native_ctxTrim(JNIEnv *env, jclass k, jlong h) {
+    gp_status st = gp_ctx_trim(CTX(h));
+    if (st != GP_OK) throw_for(env, CTX(h), st, 0);
+}
+
 /* GpPredictor.preComputeComponents -> model handle (L, alpha, LML stay in HBM) */
 JNIEXPORT jlong JNICALL Java_gpcore_Native_fitRbf(JNIEnv *env, jclass k, jlong h, jdoubleArray x, jint xoff, jint n, jint d,
                                                   jint ldx, jdoubleArray y, jdoubleArray theta, jdouble sigmaNoiseOrNaN) {

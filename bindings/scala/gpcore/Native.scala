@@ -5,6 +5,8 @@ object Native {
   System.loadLibrary("gpcore_jni")
   @native def ctxCreate(device: Int): Long
   @native def ctxDestroy(ctx: Long): Unit
+  @native def ctxTrim(ctx: Long): Unit
+  @native def dgramRbf(ctx: Long, x: Array[Double], xoff: Int, n: Int, d: Int, ldx: Int, theta: Array[Double], pos: Int, out: Array[Double]): Unit
   @native def gramRbf(ctx: Long, x: Array[Double], xoff: Int, n: Int, d: Int, ldx: Int, theta: Array[Double], out: Array[Double]): Unit
   @native def fitRbf(ctx: Long, x: Array[Double], xoff: Int, n: Int, d: Int, ldx: Int, y: Array[Double], theta: Array[Double], sigmaNoiseOrNaN: Double): Long
   @native def modelGet(ctx: Long, model: Long, what: Int, out: Array[Double], ld: Int): Unit
