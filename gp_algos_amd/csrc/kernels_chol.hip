@@ -200,8 +200,14 @@ __global__ __launch_bounds__(256) void lml_grad_trace_kernel(const double *__res
                                                              int ldk, double *__restrict__ partials, int ntiles) {
     __shared__ double xcs[TR_DMAX][TR_T];        // all d features of the tile's 64 column points
     __shared__ double wsum[4][TR_DMAX + 2];      // per wave: [0] = S_E, [1 + k] = S_k, [d + 1] = tr W
+    __shared__ double inv_s[TR_DMAX];            // 1/l_k^2: indexed at run time, so NOT left in the by-value struct (a dynamic index
+                                                 // into kernel arguments parks all 64 of them in VGPRs: 256 VGPRs, 1 wave/SIMD)
     const int tid = threadIdx.x, ti = tid & 63, tq = tid >> 6;
     for (int e = tid; e < 4 * (TR_DMAX + 2); e += 256) (&wsum[0][0])[e] = 0.0;
+    if (tid == 0) {
+#pragma unroll
+        for (int k = 0; k < TR_DMAX; ++k) inv_s[k] = prm.inv_ls2[k];   // compile-time indices: scalar loads from the argument segment
+    }
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
         int bi, bj;
         tile_lower_tr(t, bi, bj);
@@ -223,9 +229,9 @@ __global__ __launch_bounds__(256) void lml_grad_trace_kernel(const double *__res
             for (int kk = 0; kk < TR_DC; ++kk) {
                 const bool ok = kc + kk < d;
                 xi[kk] = (gi < n && ok) ? X[gi + (size_t)(kc + kk) * ldx] : 0.0;
-                inv[kk] = ok ? prm.inv_ls2[kc + kk] : 0.0;
+                inv[kk] = ok ? inv_s[kc + kk] : 0.0;
             }
-#pragma unroll
+#pragma unroll 1   // rolled: fully unrolled, the two feature passes push the kernel to 346 registers and 1 wave/SIMD
             for (int q = 0; q < 16; ++q) {
                 const int jj = tq + 4 * q;
 #pragma unroll
@@ -261,7 +267,7 @@ __global__ __launch_bounds__(256) void lml_grad_trace_kernel(const double *__res
                 xi[kk] = (gi < n && kc + kk < d) ? X[gi + (size_t)(kc + kk) * ldx] : 0.0;
                 sk[kk] = 0.0;
             }
-#pragma unroll
+#pragma unroll 1   // rolled: fully unrolled, the two feature passes push the kernel to 346 registers and 1 wave/SIMD
             for (int q = 0; q < 16; ++q) {
                 const int jj = tq + 4 * q;
 #pragma unroll
