@@ -820,10 +820,12 @@ gp_status gp_predict_dev(gp_model *mdl, const double *dXs, int m, int ldxs, doub
     GP_REQUIRE(ctx, mdl->has_x, "model was built from a Gram matrix");
     GP_REQUIRE(ctx, dXs && dmean && m >= 1 && ldxs >= m, "bad arguments");
     // The (batch x n) workspace Vt is never materialised for all m at once (config C5: 10^6 x 32768 doubles = 262 GB):
-    // test points go through in batches whose Vt stays under ~32 GiB; 65 536 rows per batch already fill the chip.
+    // test points go through in batches whose Vt stays under ~32 GiB; 65 536 rows per batch already fill the chip (one round
+    // of 512 resident tiles), 131 072 (two rounds) measured +0.9 % at n = 8192, more rows nothing (GPCORE_PREDICT_BATCH).
     const size_t budget = (size_t)32 << 30;
     int batch = (int)std::min<size_t>((size_t)m, std::max<size_t>(GP_NB, (budget / ((size_t)mdl->np * 8)) / GP_NB * GP_NB));
-    batch = std::min(batch, 65536);
+    static const int batch_cap = [] { const char *e = getenv("GPCORE_PREDICT_BATCH"); int v = e ? atoi(e) : 0; return v >= GP_NB ? v / GP_NB * GP_NB : 131072; }();
+    batch = std::min(batch, batch_cap);
     for (int lo = 0; lo < m; lo += batch) {
         const int mb = std::min(batch, m - lo);
         GP_TRY(predict_core(mdl, dXs + lo, mb, ldxs, dmean + lo, dvar ? dvar + lo : nullptr, nullptr, nullptr));
