@@ -542,6 +542,22 @@ def test_ill_conditioned_but_pd_problem(ctx):
     mdl.close()
 
 
+def test_ill_conditioned_problem_through_the_large_batch_path(ctx):
+    """Same kappa(K) ~ 1e9 problem, 24 600 test points: the folded path applies the 128x128 diagonal blocks of L as explicit
+    inverses (cond(L_ii) <= sqrt(kappa)), so it has to hold the same conditioning-limited tolerance as the substitution path."""
+    from gp_algos_amd.core import RegressionModel
+    p = synth.regression(300, 2, 24600, 31, 32, 34, np.array([2.0, 3.0, 3.0, 1e-3]))
+    mdl = RegressionModel(ctx, p["X"], p["y"], p["theta"])
+    mean, var, _ = mdl.predict(p["Xs"])                      # large-batch (Lw) path
+    m2, v2, _ = mdl.predict(p["Xs"][:500])                   # right-looking substitution path
+    Lo, ao = orc.fit(p["X"], p["y"], p["theta"])
+    om, ov, _, _ = orc.predict(p["X"], p["theta"], Lo, ao, p["Xs"][:500])
+    assert np.max(np.abs(mean[:500] - om)) <= 1e-5 and np.max(np.abs(var[:500] - ov)) <= 1e-6
+    assert np.max(np.abs(m2 - om)) <= 1e-5 and np.max(np.abs(v2 - ov)) <= 1e-6
+    assert np.max(np.abs(mean[:500] - m2)) <= 1e-6 and np.max(np.abs(var[:500] - v2)) <= 1e-7
+    mdl.close()
+
+
 def test_predict_many_points_small_model(ctx):
     """m large enough for the folded (Lw) posterior path at its default threshold, n small and not a multiple of 128."""
     from gp_algos_amd.core import RegressionModel
