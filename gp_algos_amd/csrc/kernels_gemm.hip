@@ -226,6 +226,96 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void gemm_nt_f64_kernel(int M, int
     }
 }
 
+// The posterior step on 256 x 128 tiles by ONE 16-wave workgroup per CU instead of two 8-wave workgroups on 128 x 128 tiles:
+// same waves per SIMD (4), same per-wave 64 x 32 register tile, but one barrier domain and the B tile (the Lw block row,
+// shared by every row of V^T) staged once per CU -- 48 KB instead of 64 KB of LDS-DMA per k-tile, 106 KB of LDS.
+// Measured +2.5 % on the C2 posterior (66.4 vs 68.0 ms per 65 536 points): with two independent workgroups per CU the pair
+// ran at 95 % of the pipe rate while both were resident (timestamps in DESIGN.md section 7).
+constexpr int FM = 256, FSTRIDE = FM + 16;
+__global__ __launch_bounds__(1024, 1) void gemm_rr_fused_kernel(int M, int K, const double *A, int lda, const double *__restrict__ B, int ldb,
+                                                               double *C, int ldc, gemm_rowred rr) {
+    extern __shared__ __attribute__((aligned(16))) double fsm[];
+    double *As = fsm;                           // [2][TK][FSTRIDE]
+    double *Bs = fsm + 2 * TK * FSTRIDE;        // [2][TK][LDS_STRIDE]
+    const int row0 = blockIdx.x * FM;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave & 3) * 64, wn = (wave >> 2) * 32;
+    const int fr = lane & 15, fk = lane >> 4;
+    const double *Asrc = A + row0 + lane * 2 + (size_t)wave * lda;   // wave w stages k-row w: two halves of A, one row of B
+    const double *Bsrc = B + lane * 2 + (size_t)wave * ldb;
+    auto stage = [&](int buf, int kt) {
+        const size_t koff = (size_t)kt * TK;
+        __builtin_amdgcn_global_load_lds(Asrc + koff * lda, As + (buf * TK + wave) * FSTRIDE, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(Asrc + 128 + koff * lda, As + (buf * TK + wave) * FSTRIDE + 128, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(Bsrc + koff * ldb, Bs + (buf * TK + wave) * LDS_STRIDE, 16, 0, 0);
+    };
+    double4_t acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    const int KT = K / TK;
+    stage(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < KT; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < KT) stage(cur ^ 1, kt + 1);
+        const double *Ac = As + cur * TK * FSTRIDE + wm + fr;
+        const double *Bc = Bs + cur * TK * LDS_STRIDE + wn + fr;
+#pragma unroll
+        for (int ks = 0; ks < TK / 4; ++ks) {
+            double af[4], bf[2];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) af[t] = Ac[(ks * 4 + fk) * FSTRIDE + t * 16];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) bf[t] = Bc[(ks * 4 + fk) * LDS_STRIDE + t * 16];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[nt], af[mt], acc[nt][mt], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    double rsq[4] = {0.0, 0.0, 0.0, 0.0}, rdt[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = wn + nt * 16 + fk + 4 * r;
+            const double tn = rr.dots ? rr.tvec[n] : 0.0;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const int m = row0 + wm + mt * 16 + fr;
+                const double v = acc[nt][mt][r];
+                C[m + (size_t)n * ldc] = v;
+                rsq[mt] = fma(v, v, rsq[mt]);
+                rdt[mt] = fma(v, tn, rdt[mt]);
+            }
+        }
+    double *red = fsm;   // [2][4][FM]
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        rsq[mt] += __shfl_xor(rsq[mt], 16, 64);
+        rsq[mt] += __shfl_xor(rsq[mt], 32, 64);
+        rdt[mt] += __shfl_xor(rdt[mt], 16, 64);
+        rdt[mt] += __shfl_xor(rdt[mt], 32, 64);
+        if (fk == 0) {
+            red[(wave >> 2) * FM + wm + mt * 16 + fr] = rsq[mt];
+            red[(4 + (wave >> 2)) * FM + wm + mt * 16 + fr] = rdt[mt];
+        }
+    }
+    __syncthreads();
+    if (tid < FM) {
+        double a = 0.0, b = 0.0;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { a += red[g * FM + tid]; b += red[(4 + g) * FM + tid]; }
+        rr.sumsq[row0 + tid] += a;
+        if (rr.dots) rr.dots[row0 + tid] += b;
+    }
+}
+constexpr int FUSED_LDS = (2 * TK * FSTRIDE + 2 * TK * LDS_STRIDE) * (int)sizeof(double);
+
 // register-only MFMA loop: measures the achievable fp64 matrix-core rate (roofline denominator) with 16
 // independent accumulators per wave, and stamps shader-clock / real-time counters around the loop so the
 // clock the chip holds under fp64 MFMA load and the cycles per v_mfma_f64_16x16x4_f64 can be read off.
@@ -294,6 +384,19 @@ void gpk_gemm_nt(hipStream_t s, int M, int N, int K, double alpha, const double 
 void gpk_gemm_nt_rowred(hipStream_t s, int M, int N, int K, const double *A, int lda, const double *B, int ldb, double *C, int ldc,
                         double *sumsq, const double *tvec, double *dots) {
     if (M <= 0 || N != TN) return;   // one column tile: a tile is the only writer of its rows' accumulators
+    // 256-row tiles by one 16-wave workgroup per CU where they fit (GPCORE_GEMM_FUSED=0: always two 8-wave workgroups on
+    // 128-row tiles); an odd 128-row remainder goes through the 8-wave kernel below
+    static const bool fused = [] { const char *e = getenv("GPCORE_GEMM_FUSED"); return !e || atoi(e) != 0; }();
+    static const bool fused_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_rr_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS) == hipSuccess;
+    if (fused && fused_ok && M >= FM) {
+        const int Mf = M / FM * FM;
+        gemm_rowred r2;
+        r2.sumsq = sumsq, r2.tvec = tvec, r2.dots = dots;
+        hipLaunchKernelGGL(gemm_rr_fused_kernel, dim3(Mf / FM), dim3(1024), FUSED_LDS, s, Mf, K, A, lda, B, ldb, C, ldc, r2);
+        if (Mf == M) return;
+        A += Mf, C += Mf, sumsq += Mf, M -= Mf;
+        if (dots) dots += Mf;
+    }
     static const int nw = [] { const char *e = getenv("GPCORE_GEMM_WAVES"); return (e && atoi(e) == 4) ? 4 : 8; }();
     gemm_rowred rr;
     rr.sumsq = sumsq, rr.tvec = tvec, rr.dots = dots;
