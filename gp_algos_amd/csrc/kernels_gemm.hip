@@ -18,6 +18,7 @@
 // so each lane's accumulator holds 4 consecutive-n values at one m: stores are 128-B row segments
 // of column-major C.
 #include "gpcore_internal.h"
+#include <algorithm>
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 typedef double double2_t __attribute__((ext_vector_type(2)));
@@ -232,17 +233,43 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void gemm_nt_f64_kernel(int M, int
 // Measured +2.5 % on the C2 posterior (66.4 vs 68.0 ms per 65 536 points): with two independent workgroups per CU the pair
 // ran at 95 % of the pipe rate while both were resident (timestamps in DESIGN.md section 7).
 constexpr int FM = 256, FSTRIDE = FM + 16;
-__global__ __launch_bounds__(1024, 1) void gemm_rr_fused_kernel(int M, int K, const double *A, int lda, const double *__restrict__ B, int ldb,
-                                                               double *C, int ldc, gemm_rowred rr) {
+// LOWER: tiles (bi, bj) of 256 x 128 whose last row reaches the diagonal (256 bi + 255 >= 128 bj); elements above the diagonal
+// are computed and not stored.  Tile rows are enumerated bi ascending, bj ascending inside.
+template <int LOWER, int HAS_BETA, int RR>
+__global__ __launch_bounds__(1024, 1) void gemm_fused_kernel(int M, int N, int K, double alpha, const double *A, int lda, const double *B, int ldb,
+                                                            double beta, double *C, int ldc, gp_batch bt, gemm_rowred rr) {
     extern __shared__ __attribute__((aligned(16))) double fsm[];
     double *As = fsm;                           // [2][TK][FSTRIDE]
     double *Bs = fsm + 2 * TK * FSTRIDE;        // [2][TK][LDS_STRIDE]
-    const int row0 = blockIdx.x * FM;
+    const int nbm = M / FM, nbn = N / TN;
+    int bi, bj;
+    if (LOWER) {
+        int t = blockIdx.x;
+        bi = 0;
+        for (;;) {   // row bi holds min(nbn, 2 bi + 2) tiles
+            const int cnt = (2 * bi + 2 < nbn) ? 2 * bi + 2 : nbn;
+            if (t < cnt) break;
+            t -= cnt;
+            ++bi;
+        }
+        bj = t;
+    } else {
+        // XCD-aware: consecutive block ids round-robin over the 8 XCDs; give each XCD a contiguous run of tiles sharing a B panel
+        const int nwg = gridDim.x, id = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = id & 7;
+        const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+        bi = swz % nbm;
+        bj = swz / nbm;
+    }
+    A += (size_t)blockIdx.y * bt.s0;
+    B += (size_t)blockIdx.y * bt.s1;
+    C += (size_t)blockIdx.y * bt.s2;
+    const int row0 = bi * FM, col0 = bj * TN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = (wave & 3) * 64, wn = (wave >> 2) * 32;
     const int fr = lane & 15, fk = lane >> 4;
     const double *Asrc = A + row0 + lane * 2 + (size_t)wave * lda;   // wave w stages k-row w: two halves of A, one row of B
-    const double *Bsrc = B + lane * 2 + (size_t)wave * ldb;
+    const double *Bsrc = B + col0 + lane * 2 + (size_t)wave * ldb;
     auto stage = [&](int buf, int kt) {
         const size_t koff = (size_t)kt * TK;
         __builtin_amdgcn_global_load_lds(Asrc + koff * lda, As + (buf * TK + wave) * FSTRIDE, 16, 0, 0);
@@ -255,7 +282,7 @@ __global__ __launch_bounds__(1024, 1) void gemm_rr_fused_kernel(int M, int K, co
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
     const int KT = K / TK;
-    stage(0, 0);
+    if (KT > 0) stage(0, 0);
     __syncthreads();
     for (int kt = 0; kt < KT; ++kt) {
         const int cur = kt & 1;
@@ -277,41 +304,60 @@ __global__ __launch_bounds__(1024, 1) void gemm_rr_fused_kernel(int M, int K, co
         }
         __syncthreads();
     }
+    const bool diag = LOWER && (row0 < col0 + TN);   // the tile touches or crosses the diagonal
     double rsq[4] = {0.0, 0.0, 0.0, 0.0}, rdt[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
+    for (int nt = 0; nt < 2; ++nt) {
+        double cv[4][4];
+        if (HAS_BETA) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = col0 + wn + nt * 16 + fk + 4 * r;
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    const int m = row0 + wm + mt * 16 + fr;
+                    cv[r][mt] = (diag && m < n) ? 0.0 : C[m + (size_t)n * ldc];
+                }
+            }
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int n = wn + nt * 16 + fk + 4 * r;
-            const double tn = rr.dots ? rr.tvec[n] : 0.0;
+            const int n = col0 + wn + nt * 16 + fk + 4 * r;
+            const double tn = (RR && rr.dots) ? rr.tvec[n] : 0.0;
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
                 const int m = row0 + wm + mt * 16 + fr;
-                const double v = acc[nt][mt][r];
-                C[m + (size_t)n * ldc] = v;
-                rsq[mt] = fma(v, v, rsq[mt]);
-                rdt[mt] = fma(v, tn, rdt[mt]);
+                double v = alpha * acc[nt][mt][r];
+                if (HAS_BETA) v = fma(beta, cv[r][mt], v);
+                if (!(diag && m < n)) C[m + (size_t)n * ldc] = v;
+                if (RR) {
+                    rsq[mt] = fma(v, v, rsq[mt]);
+                    rdt[mt] = fma(v, tn, rdt[mt]);
+                }
             }
         }
-    double *red = fsm;   // [2][4][FM]
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        rsq[mt] += __shfl_xor(rsq[mt], 16, 64);
-        rsq[mt] += __shfl_xor(rsq[mt], 32, 64);
-        rdt[mt] += __shfl_xor(rdt[mt], 16, 64);
-        rdt[mt] += __shfl_xor(rdt[mt], 32, 64);
-        if (fk == 0) {
-            red[(wave >> 2) * FM + wm + mt * 16 + fr] = rsq[mt];
-            red[(4 + (wave >> 2)) * FM + wm + mt * 16 + fr] = rdt[mt];
-        }
     }
-    __syncthreads();
-    if (tid < FM) {
-        double a = 0.0, b = 0.0;
+    if (RR) {
+        double *red = fsm;   // [2][4][FM]
 #pragma unroll
-        for (int g = 0; g < 4; ++g) { a += red[g * FM + tid]; b += red[(4 + g) * FM + tid]; }
-        rr.sumsq[row0 + tid] += a;
-        if (rr.dots) rr.dots[row0 + tid] += b;
+        for (int mt = 0; mt < 4; ++mt) {
+            rsq[mt] += __shfl_xor(rsq[mt], 16, 64);
+            rsq[mt] += __shfl_xor(rsq[mt], 32, 64);
+            rdt[mt] += __shfl_xor(rdt[mt], 16, 64);
+            rdt[mt] += __shfl_xor(rdt[mt], 32, 64);
+            if (fk == 0) {
+                red[(wave >> 2) * FM + wm + mt * 16 + fr] = rsq[mt];
+                red[(4 + (wave >> 2)) * FM + wm + mt * 16 + fr] = rdt[mt];
+            }
+        }
+        __syncthreads();
+        if (tid < FM) {
+            double a = 0.0, b = 0.0;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) { a += red[g * FM + tid]; b += red[(4 + g) * FM + tid]; }
+            rr.sumsq[row0 + tid] += a;
+            if (rr.dots) rr.dots[row0 + tid] += b;
+        }
     }
 }
 constexpr int FUSED_LDS = (2 * TK * FSTRIDE + 2 * TK * LDS_STRIDE) * (int)sizeof(double);
@@ -352,6 +398,9 @@ void gpk_gemm_nt(hipStream_t s, int M, int N, int K, double alpha, const double 
     if (M <= 0 || N <= 0 || bt.count <= 0) return;
     const gemm_rowred rr;
     const bool hb = beta != 0.0;
+    // (The 256 x 128 / 16-wave tile of the posterior step was also tried here for the general launches: C3 658-663 vs 668-675
+    // settings/s, C4 75.8 vs 82.3 sweeps/s -- with several column tiles per launch and short k its unhidden prologue and
+    // epilogue cost more than the shared B tile saves.  Not used.)
     // 8 waves per workgroup (64 x 32 per wave, 4 waves/SIMD at 2 workgroups/CU) measured equal to 4 waves (64 x 64 per wave) on
     // long-K launches (65 TFLOP/s both) and ~5 % better on the short-K Cholesky updates; GPCORE_GEMM_WAVES=4 selects the other.
     static const int nw = [] { const char *e = getenv("GPCORE_GEMM_WAVES"); return (e && atoi(e) == 4) ? 4 : 8; }();
@@ -387,12 +436,12 @@ void gpk_gemm_nt_rowred(hipStream_t s, int M, int N, int K, const double *A, int
     // 256-row tiles by one 16-wave workgroup per CU where they fit (GPCORE_GEMM_FUSED=0: always two 8-wave workgroups on
     // 128-row tiles); an odd 128-row remainder goes through the 8-wave kernel below
     static const bool fused = [] { const char *e = getenv("GPCORE_GEMM_FUSED"); return !e || atoi(e) != 0; }();
-    static const bool fused_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_rr_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS) == hipSuccess;
+    static const bool fused_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_fused_kernel<0, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS) == hipSuccess;
     if (fused && fused_ok && M >= FM) {
         const int Mf = M / FM * FM;
         gemm_rowred r2;
         r2.sumsq = sumsq, r2.tvec = tvec, r2.dots = dots;
-        hipLaunchKernelGGL(gemm_rr_fused_kernel, dim3(Mf / FM), dim3(1024), FUSED_LDS, s, Mf, K, A, lda, B, ldb, C, ldc, r2);
+        hipLaunchKernelGGL((gemm_fused_kernel<0, 0, 1>), dim3(Mf / FM), dim3(1024), FUSED_LDS, s, Mf, TN, K, 1.0, A, lda, B, ldb, 0.0, C, ldc, gp_batch(), r2);
         if (Mf == M) return;
         A += Mf, C += Mf, sumsq += Mf, M -= Mf;
         if (dots) dots += Mf;
