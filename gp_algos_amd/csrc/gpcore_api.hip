@@ -435,7 +435,7 @@ gp_status gp_ctx_create(int device, void *stream, gp_ctx **out) {
     if (e == hipSuccess) e = hipMalloc(&ctx->d_scalars, sizeof(double) * 256);
     if (e == hipSuccess) e = hipMalloc(&ctx->d_info, sizeof(int) * 4);
     if (e == hipSuccess) e = hipMemset(ctx->d_info, 0, sizeof(int) * 4);
-    if (e == hipSuccess && gpk_init_diag_kernels() != 0) e = hipErrorInvalidValue;
+    if (e == hipSuccess && (gpk_init_diag_kernels() != 0 || gpk_init_gemm_kernels() != 0)) e = hipErrorInvalidValue;
     if (e != hipSuccess) { delete ctx; return GP_EHIP; }
     *out = ctx;
     return GP_OK;

@@ -118,6 +118,7 @@ void gpk_var_finish(hipStream_t s, double *var, const double *sumsq, int m, doub
 void gpk_copy_2d(hipStream_t s, double *dst, int ldd, const double *src, int lds, int rows, int cols);
 double gpk_probe_mfma(hipStream_t s, int num_cu, int waves_per_simd, double *clock_mhz, double *cycles_per_mfma);
 int gpk_init_diag_kernels();
+int gpk_init_gemm_kernels();
 // MFMA-blocked critical-path kernels (kernels_diag.hip).  dinv holds the inverses of the 16x16 diagonal
 // tiles of L: tile b (rows 16b..16b+15) at dinv + 256*b, element (c,k) at c + 16k; a 128-block owns 8 tiles.
 void gpk_potrf_diag128(hipStream_t s, double *A, int lda, double *dinv_k, int *d_info, int base, gp_batch bt = gp_batch());   // strides: A, dinv; d_info + 1 per problem

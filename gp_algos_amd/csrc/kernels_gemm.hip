@@ -430,14 +430,18 @@ void gpk_gemm_nt(hipStream_t s, int M, int N, int K, double alpha, const double 
 
 // C = A B^T (no beta) with the row reductions above; C may alias the last N columns of A (each tile reads only its own
 // rows of A and stores after its k loop) -- the in-place posterior step.
+// per device, from gp_ctx_create: the fused kernel's 106 KB of LDS is above the default dynamic limit
+int gpk_init_gemm_kernels() {
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_fused_kernel<0, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS) == hipSuccess ? 0 : 1;
+}
+
 void gpk_gemm_nt_rowred(hipStream_t s, int M, int N, int K, const double *A, int lda, const double *B, int ldb, double *C, int ldc,
                         double *sumsq, const double *tvec, double *dots) {
     if (M <= 0 || N != TN) return;   // one column tile: a tile is the only writer of its rows' accumulators
     // 256-row tiles by one 16-wave workgroup per CU where they fit (GPCORE_GEMM_FUSED=0: always two 8-wave workgroups on
     // 128-row tiles); an odd 128-row remainder goes through the 8-wave kernel below
     static const bool fused = [] { const char *e = getenv("GPCORE_GEMM_FUSED"); return !e || atoi(e) != 0; }();
-    static const bool fused_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_fused_kernel<0, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS) == hipSuccess;
-    if (fused && fused_ok && M >= FM) {
+    if (fused && M >= FM) {
         const int Mf = M / FM * FM;
         gemm_rowred r2;
         r2.sumsq = sumsq, r2.tvec = tvec, r2.dots = dots;
