@@ -102,7 +102,7 @@ def test_c2_large_batch_path_agrees_with_small_batch_path_and_oracle(c2):
 
 
 def test_odd_sizes_through_the_padded_large_batch_path():
-    """n = 5000 (padded to 5120), d = 5, m = 25000 (padded to 25088): identities at the training inputs and the two posterior
+    """n = 5000 (padded to 5120), d = 5, m = 25100 (padded to 25216, an odd number of 128-row tiles): identities at the training inputs and the two posterior
     code paths against each other."""
     from gp_algos_amd.core import Context, RegressionModel
     p = synth.regression(5000, 5, 25000, 71, 72, 73, synth.ard_theta(5, 1.2, 1.0, 0.15))
@@ -112,7 +112,7 @@ def test_odd_sizes_through_the_padded_large_batch_path():
         alpha = mdl.alpha()
         Ka = _kmatvec(p["X"], p["theta"], alpha[:, None])[:, 0]
         assert np.max(np.abs(Ka - p["y"])) <= 1e-9 * np.max(np.abs(p["y"]))
-        both = np.asfortranarray(np.vstack([p["X"][:1000], p["Xs"][:24000]]))      # 25000 rows: large-batch path
+        both = np.asfortranarray(np.vstack([p["X"][:1000], p["Xs"][:24100]]))      # 25100 rows -> 25216 padded = 98 tiles of 256 + one of 128
         mean, var, _ = mdl.predict(both)
         assert np.max(np.abs(mean[:1000] - (p["y"][:1000] - sn2 * alpha[:1000]))) <= 1e-8     # K* = K - sn^2 I at training inputs
         m2, v2, _ = mdl.predict(np.asfortranarray(both[900:1300]))                    # small batch: right-looking path

@@ -580,7 +580,7 @@ sys.path.insert(0, sys.argv[1])
 from gp_algos_amd import core, synth
 from oracle import gp_oracle as orc
 ctx = core.Context(0)
-p = synth.config_c2(700, 5, 900)
+p = synth.config_c2(700, 5, 1100)     # 1152 padded rows = 4 tiles of 256 + one of 128: both posterior GEMM kernels run
 model = core.RegressionModel(ctx, p["X"], p["y"], p["theta"])
 mean, var = model.predict(p["Xs"])[:2]
 L, alpha = orc.fit(p["X"], p["y"], p["theta"])
