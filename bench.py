@@ -159,7 +159,7 @@ def run_secondary(args):
 
 
 PMC_SUMMARY = "r01_e_pmc_c2_summary.json"
-DOMINANT_KERNEL = "gemm_fused_kernel<0,0,1>"
+DOMINANT_KERNEL = "gemm_fused_kernel<0,0,1,8>"
 
 
 def cpu_opt_baseline(p, sample_pts=4096):
@@ -321,7 +321,7 @@ def main():
                                    "test points per GPU" % (n, d, m), "n": n, "d": d, "m_per_gpu": m,
                        "parallelism": "test points sharded %d-way, model refit per rank, no data-path collective" % world},
             "roofline": {"kernel": DOMINANT_KERNEL + " (posterior step Vt_i = Vt[:, :128(i+1)] Lw_i^T: update and panel solve of block "
-                                   "column i in one product on 256x128 tiles, one 16-wave workgroup per CU, row reductions in the "
+                                   "column i in one product on 256x128 tiles, one 8-wave workgroup (64x64 per wave) per CU, row reductions in the "
                                    "epilogue; v_mfma_f64_16x16x4_f64)",
                          "bound": "mfma", "achieved": gemm_tflops, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": gemm_tflops / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic,

@@ -227,16 +227,16 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void gemm_nt_f64_kernel(int M, int
     }
 }
 
-// The posterior step on 256 x 128 tiles by ONE 16-wave workgroup per CU instead of two 8-wave workgroups on 128 x 128 tiles:
-// same waves per SIMD (4), same per-wave 64 x 32 register tile, but one barrier domain and the B tile (the Lw block row,
-// shared by every row of V^T) staged once per CU -- 48 KB instead of 64 KB of LDS-DMA per k-tile, 106 KB of LDS.
+// The posterior step on 256 x 128 tiles by ONE workgroup per CU (16 waves x 64x32, or 8 waves x 64x64 = default) instead of two
+// 8-wave workgroups on 128 x 128 tiles: one barrier domain and the B tile (the Lw block row, shared by every row of V^T)
+// staged once per CU -- 48 KB instead of 64 KB of LDS-DMA per k-tile, 106 KB of LDS.
 // Measured +2.5 % on the C2 posterior (66.4 vs 68.0 ms per 65 536 points): with two independent workgroups per CU the pair
 // ran at 95 % of the pipe rate while both were resident (timestamps in DESIGN.md section 7).
 constexpr int FM = 256, FSTRIDE = FM + 16;
 // LOWER: tiles (bi, bj) of 256 x 128 whose last row reaches the diagonal (256 bi + 255 >= 128 bj); elements above the diagonal
 // are computed and not stored.  Tile rows are enumerated bi ascending, bj ascending inside.
-template <int LOWER, int HAS_BETA, int RR>
-__global__ __launch_bounds__(1024, 1) void gemm_fused_kernel(int M, int N, int K, double alpha, const double *A, int lda, const double *B, int ldb,
+template <int LOWER, int HAS_BETA, int RR, int WV = 16>
+__global__ __launch_bounds__(WV * 64, 1) void gemm_fused_kernel(int M, int N, int K, double alpha, const double *A, int lda, const double *B, int ldb,
                                                             double beta, double *C, int ldc, gp_batch bt, gemm_rowred rr) {
     extern __shared__ __attribute__((aligned(16))) double fsm[];
     double *As = fsm;                           // [2][TK][FSTRIDE]
@@ -266,19 +266,24 @@ __global__ __launch_bounds__(1024, 1) void gemm_fused_kernel(int M, int N, int K
     C += (size_t)blockIdx.y * bt.s2;
     const int row0 = bi * FM, col0 = bj * TN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = (wave & 3) * 64, wn = (wave >> 2) * 32;
+    constexpr int NT = (WV == 16) ? 2 : 4;      // 16-column accumulator tiles per wave: 64 x 32 (16 waves) or 64 x 64 (8 waves)
+    const int wm = (wave & 3) * 64, wn = (wave >> 2) * (NT * 16);
     const int fr = lane & 15, fk = lane >> 4;
-    const double *Asrc = A + row0 + lane * 2 + (size_t)wave * lda;   // wave w stages k-row w: two halves of A, one row of B
+    const double *Asrc = A + row0 + lane * 2 + (size_t)wave * lda;   // wave w stages k-rows w, w + WV, ...: two halves of A, one row of B
     const double *Bsrc = B + col0 + lane * 2 + (size_t)wave * ldb;
     auto stage = [&](int buf, int kt) {
         const size_t koff = (size_t)kt * TK;
-        __builtin_amdgcn_global_load_lds(Asrc + koff * lda, As + (buf * TK + wave) * FSTRIDE, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(Asrc + 128 + koff * lda, As + (buf * TK + wave) * FSTRIDE + 128, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(Bsrc + koff * ldb, Bs + (buf * TK + wave) * LDS_STRIDE, 16, 0, 0);
-    };
-    double4_t acc[2][4];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+        for (int q = 0; q < TK / WV; ++q) {
+            const int kr = wave + WV * q;
+            __builtin_amdgcn_global_load_lds(Asrc + (koff + WV * q) * lda, As + (buf * TK + kr) * FSTRIDE, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(Asrc + 128 + (koff + WV * q) * lda, As + (buf * TK + kr) * FSTRIDE + 128, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(Bsrc + (koff + WV * q) * ldb, Bs + (buf * TK + kr) * LDS_STRIDE, 16, 0, 0);
+        }
+    };
+    double4_t acc[NT][4];
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
     const int KT = K / TK;
@@ -291,13 +296,13 @@ __global__ __launch_bounds__(1024, 1) void gemm_fused_kernel(int M, int N, int K
         const double *Bc = Bs + cur * TK * LDS_STRIDE + wn + fr;
 #pragma unroll
         for (int ks = 0; ks < TK / 4; ++ks) {
-            double af[4], bf[2];
+            double af[4], bf[NT];
 #pragma unroll
             for (int t = 0; t < 4; ++t) af[t] = Ac[(ks * 4 + fk) * FSTRIDE + t * 16];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) bf[t] = Bc[(ks * 4 + fk) * LDS_STRIDE + t * 16];
+            for (int t = 0; t < NT; ++t) bf[t] = Bc[(ks * 4 + fk) * LDS_STRIDE + t * 16];
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
+            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt)
                     acc[nt][mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[nt], af[mt], acc[nt][mt], 0, 0, 0);
@@ -307,7 +312,7 @@ __global__ __launch_bounds__(1024, 1) void gemm_fused_kernel(int M, int N, int K
     const bool diag = LOWER && (row0 < col0 + TN);   // the tile touches or crosses the diagonal
     double rsq[4] = {0.0, 0.0, 0.0, 0.0}, rdt[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
+    for (int nt = 0; nt < NT; ++nt) {
         double cv[4][4];
         if (HAS_BETA) {
 #pragma unroll
@@ -338,7 +343,8 @@ __global__ __launch_bounds__(1024, 1) void gemm_fused_kernel(int M, int N, int K
         }
     }
     if (RR) {
-        double *red = fsm;   // [2][4][FM]
+        constexpr int NG = WV / 4;   // column groups of waves
+        double *red = fsm;   // [2][NG][FM]
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
             rsq[mt] += __shfl_xor(rsq[mt], 16, 64);
@@ -347,14 +353,14 @@ __global__ __launch_bounds__(1024, 1) void gemm_fused_kernel(int M, int N, int K
             rdt[mt] += __shfl_xor(rdt[mt], 32, 64);
             if (fk == 0) {
                 red[(wave >> 2) * FM + wm + mt * 16 + fr] = rsq[mt];
-                red[(4 + (wave >> 2)) * FM + wm + mt * 16 + fr] = rdt[mt];
+                red[(NG + (wave >> 2)) * FM + wm + mt * 16 + fr] = rdt[mt];
             }
         }
         __syncthreads();
         if (tid < FM) {
             double a = 0.0, b = 0.0;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) { a += red[g * FM + tid]; b += red[(4 + g) * FM + tid]; }
+            for (int g = 0; g < NG; ++g) { a += red[g * FM + tid]; b += red[(NG + g) * FM + tid]; }
             rr.sumsq[row0 + tid] += a;
             if (rr.dots) rr.dots[row0 + tid] += b;
         }
@@ -432,7 +438,9 @@ void gpk_gemm_nt(hipStream_t s, int M, int N, int K, double alpha, const double 
 // rows of A and stores after its k loop) -- the in-place posterior step.
 // per device, from gp_ctx_create: the fused kernel's 106 KB of LDS is above the default dynamic limit
 int gpk_init_gemm_kernels() {
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_fused_kernel<0, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS) == hipSuccess ? 0 : 1;
+    const bool a = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_fused_kernel<0, 0, 1, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS) == hipSuccess;
+    const bool b = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_fused_kernel<0, 0, 1, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS) == hipSuccess;
+    return (a && b) ? 0 : 1;
 }
 
 void gpk_gemm_nt_rowred(hipStream_t s, int M, int N, int K, const double *A, int lda, const double *B, int ldb, double *C, int ldc,
@@ -445,7 +453,11 @@ void gpk_gemm_nt_rowred(hipStream_t s, int M, int N, int K, const double *A, int
         const int Mf = M / FM * FM;
         gemm_rowred r2;
         r2.sumsq = sumsq, r2.tvec = tvec, r2.dots = dots;
-        hipLaunchKernelGGL((gemm_fused_kernel<0, 0, 1>), dim3(Mf / FM), dim3(1024), FUSED_LDS, s, Mf, TN, K, 1.0, A, lda, B, ldb, 0.0, C, ldc, gp_batch(), r2);
+        static const bool w8 = [] { const char *e = getenv("GPCORE_FUSED_WAVES"); return !(e && atoi(e) == 16); }();   // 8 waves x 64x64 measured +0.6 % over 16 x 64x32 (a third fewer LDS fragment reads; the loop is power-limited)
+        if (w8)
+            hipLaunchKernelGGL((gemm_fused_kernel<0, 0, 1, 8>), dim3(Mf / FM), dim3(512), FUSED_LDS, s, Mf, TN, K, 1.0, A, lda, B, ldb, 0.0, C, ldc, gp_batch(), r2);
+        else
+            hipLaunchKernelGGL((gemm_fused_kernel<0, 0, 1>), dim3(Mf / FM), dim3(1024), FUSED_LDS, s, Mf, TN, K, 1.0, A, lda, B, ldb, 0.0, C, ldc, gp_batch(), r2);
         if (Mf == M) return;
         A += Mf, C += Mf, sumsq += Mf, M -= Mf;
         if (dots) dots += Mf;
