@@ -127,7 +127,7 @@ def run_secondary(args):
                               "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                               "dtype": "f64", "data": "synthetic",
                               "config": {"workload": "C5: n=%d d=%d fit once per GPU (first fit incl. allocation %.0f ms), %d test points per GPU "
-                                                     "per step in batches of 65536" % (n, args.d, t_fit * 1e3, m), "n": n, "m_per_gpu": m},
+                                                     "per step in batches of up to 131072 rows (Vt <= 32 GiB)" % (n, args.d, t_fit * 1e3, m), "n": n, "m_per_gpu": m},
                               "tflops_n2m": float(n) * n * m * args.steps / dt / 1e12 * world,
                               "var_range": [float(var.min()), float(var.max())]}), flush=True)
         lib.gp_model_destroy(h)
