@@ -10,8 +10,11 @@ from oracle import gp_oracle as orc
 pytestmark = pytest.mark.gpu
 
 edge = st.sampled_from([1, 2, 15, 16, 17, 63, 64, 65, 127, 128, 129, 191, 255, 256, 257, 300])
-COMMON = dict(deadline=None, max_examples=60, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow],
-              derandomize=True)
+import os
+
+SCALE = int(os.environ.get("GPCORE_TEST_EXAMPLES_SCALE", "1"))   # soak runs: more draws from the same strategies
+COMMON = dict(deadline=None, max_examples=60 * SCALE, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow],
+              derandomize=(SCALE == 1))
 
 
 @pytest.fixture(scope="module")
@@ -58,7 +61,7 @@ def test_lml_gradient_random_shapes(ctx, n, d, B, seed):
         assert np.max(np.abs(grad[b] - og)) <= 1e-8 * max(1e-3, np.max(np.abs(og)))
 
 
-@settings(**{**COMMON, "max_examples": 25})
+@settings(**{**COMMON, "max_examples": 25 * SCALE})
 @given(n=st.sampled_from([2, 17, 100, 128, 129, 260]), sweeps=st.integers(1, 3), seed=st.integers(0, 10 ** 6))
 def test_ep_random_shapes(ctx, n, sweeps, seed):
     from gp_algos_amd.core import EpClassifierState
