@@ -119,18 +119,29 @@ __global__ __launch_bounds__(192) void ep_block_kernel(int n, int np, int i0, in
     // longest thing in an iteration: 128^2/2 dependent LDS round trips per block).
     const int lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
     const int jtiles = (bsz + 15) >> 4;
+    double *cf = sc + 8 + 3 * GP_NB;   // coef of every processed site (rows read it one iteration later)
+    double *pub = cf + GP_NB;          // [2][3]: what the scalar lane needs to start a site: P, B, M (see below), by site parity
+    // One barrier per site.  The scalar lane of wave 2 runs the serial chain of site t (erf, exp, reciprocals) while the row
+    // threads, one site BEHIND it, (i) finish column t with site t-1's result and update the mean, (ii) build the part of
+    // column t+1 that does not depend on site t (q < t, at most 14 terms of the current 16-site chunk) and (iii) row thread
+    // t+1 publishes P = that partial diagonal entry, B = S[t+1, t] and M = mu_{t+1} so far; after the barrier the scalar lane
+    // gets its inputs as  s_ii = P - c_t B^2,  mu_i = M + B coef_t  from its own registers and goes straight into the next
+    // chain.  At a chunk boundary the 16 finished columns are applied to all later columns on the matrix cores.
+    if (tid == 0) { pub[0] = A[0]; pub[1] = 0.0; pub[2] = mb[0]; }
+    __syncthreads();
+    double part = 0.0, c_prev = 0.0, coef_prev = 0.0;
     for (int t = 0; t < bsz; ++t) {
         const int cs0 = t & ~15;
-        const bool boundary = ((t + 1) & 15) == 0;          // site t closes its chunk
-        const bool next_col = (t + 1 < bsz) && !boundary;   // column t+1 is completed by this iteration's row threads
-        double part = 0.0;
+        const bool first = (t & 15) == 0;                    // first site of a chunk: its column has no pending term
+        const bool boundary = ((t + 1) & 15) == 0;           // site t closes its chunk
+        const bool build_next = (t + 1 < bsz) && !boundary;  // row threads prepare column t+1 in this iteration
         if (!rowthread) {
             if (tid == GP_NB) {
-                // Site update, EpParameterEstimator.scala:45-53 + marginalMoments :98-109, with the divisions folded:
-                // the reference's 12 divisions and 2 square roots become 5 Newton reciprocals and one rsqrt.  Same formulas,
-                // re-associated; fp64 throughout.
                 const int i = i0 + t;
-                const double sii = Sb[t + t * LS], mui = mb[t];
+                const double *pb = pub + 3 * (t & 1);
+                const double Bv = pb[1];
+                const double sii = fma(-c_prev * Bv, Bv, pb[0]);
+                const double mui = fma(Bv, coef_prev, pb[2]);
                 const double to = tb[t], no = nb[t];
                 const double rs = rcp_nr(sii);
                 const double tc = rs - to;                              // cavity tau  :45
@@ -150,56 +161,53 @@ __global__ __launch_bounds__(192) void ep_block_kernel(int n, int np, int i0, in
                 const double c = dtau * rcp_nr(fma(dtau, sii, 1.0));     // 1/(1/dtau + sii), finite at dtau = 0  :53
                 const double dnu = nn - no;
                 const double coef = dnu - c * (mui + dnu * sii);
-                sc[0] = coef;
                 cs[t] = c;
+                cf[t] = coef;
+                c_prev = c, coef_prev = coef;
                 tau[i] = tn; nu[i] = nn; cav_tau[i] = tc; cav_nu[i] = nc;
                 cvec[t] = c;
                 ncoef[t] = coef;
             }
-        } else if (next_col && r > t) {
-            double p0 = A[r + (t + 1) * LS], p1 = 0.0, p2 = 0.0, p3 = 0.0;
-            int q = cs0;
-            for (; q + 8 <= t; q += 8) {
-                // all 24 LDS reads of the group first, then the arithmetic: left alone the scheduler sometimes interleaves
-                // read / wait / fma one pair at a time
-                double cq[8], sq[8], sr[8];
+        } else {
+            if (!first && r >= t) {     // site t-1's result: mean, and column t becomes final
+                const double st = Sb[r + (t - 1) * LS];
+                mb[r] = fma(st, cf[t - 1], mb[r]);
+                const double wt = cs[t - 1] * Sb[t + (t - 1) * LS];
+                Sb[r + t * LS] = fma(-wt, st, part);
+            }
+            if (build_next && r > t) {
+                double p0 = A[r + (t + 1) * LS], p1 = 0.0, p2 = 0.0, p3 = 0.0;
+                int q = cs0;
+                for (; q + 4 <= t; q += 4) {
+                    double cq[4], sq[4], sr[4];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    cq[u] = cs[q + u];
-                    sq[u] = Sb[(t + 1) + (q + u) * LS];
-                    sr[u] = Sb[r + (q + u) * LS];
+                    for (int u = 0; u < 4; ++u) {
+                        cq[u] = cs[q + u];
+                        sq[u] = Sb[(t + 1) + (q + u) * LS];
+                        sr[u] = Sb[r + (q + u) * LS];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    p0 = fma(-(cq[0] * sq[0]), sr[0], p0);
+                    p1 = fma(-(cq[1] * sq[1]), sr[1], p1);
+                    p2 = fma(-(cq[2] * sq[2]), sr[2], p2);
+                    p3 = fma(-(cq[3] * sq[3]), sr[3], p3);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                __builtin_amdgcn_sched_barrier(0);
-                p0 = fma(-(cq[0] * sq[0]), sr[0], p0);
-                p1 = fma(-(cq[1] * sq[1]), sr[1], p1);
-                p2 = fma(-(cq[2] * sq[2]), sr[2], p2);
-                p3 = fma(-(cq[3] * sq[3]), sr[3], p3);
-                p0 = fma(-(cq[4] * sq[4]), sr[4], p0);
-                p1 = fma(-(cq[5] * sq[5]), sr[5], p1);
-                p2 = fma(-(cq[6] * sq[6]), sr[6], p2);
-                p3 = fma(-(cq[7] * sq[7]), sr[7], p3);
-                __builtin_amdgcn_sched_barrier(0);
+                for (; q < t; ++q) p0 = fma(-(cs[q] * Sb[(t + 1) + q * LS]), Sb[r + q * LS], p0);
+                part = (p0 + p1) + (p2 + p3);
+                if (r == t + 1) {
+                    double *pb = pub + 3 * ((t + 1) & 1);
+                    pb[0] = part;
+                    pb[1] = Sb[(t + 1) + t * LS];     // column t is final for this row: written by this thread just above
+                    pb[2] = mb[r];
+                }
             }
-            for (; q + 4 <= t; q += 4) {
-                p0 = fma(-(cs[q] * Sb[(t + 1) + q * LS]), Sb[r + q * LS], p0);
-                p1 = fma(-(cs[q + 1] * Sb[(t + 1) + (q + 1) * LS]), Sb[r + (q + 1) * LS], p1);
-                p2 = fma(-(cs[q + 2] * Sb[(t + 1) + (q + 2) * LS]), Sb[r + (q + 2) * LS], p2);
-                p3 = fma(-(cs[q + 3] * Sb[(t + 1) + (q + 3) * LS]), Sb[r + (q + 3) * LS], p3);
-            }
-            for (; q < t; ++q) p0 = fma(-(cs[q] * Sb[(t + 1) + q * LS]), Sb[r + q * LS], p0);
-            part = (p0 + p1) + (p2 + p3);
         }
         __syncthreads();
-        if (rowthread && r > t) {
-            const double st = Sb[r + t * LS];
-            mb[r] = fma(st, sc[0], mb[r]);
-            if (next_col) {
-                const double wt = cs[t] * Sb[(t + 1) + t * LS];   // c_t * S[i_{t+1}, t]
-                Sb[r + (t + 1) * LS] = fma(-wt, st, part);
-            }
-        }
         if (boundary && t + 1 < bsz) {
-            // chunk update on the matrix cores, all three waves; tiles (I, J), jc <= J <= I < 8, J < jtiles
+            // the chunk is complete (column t became final above, c_t is known): mean for site t, then the chunk's 16 columns are
+            // applied to every later column of the block on the matrix cores -- tiles (I, J), jc <= J <= I < 8, J < jtiles
+            if (rowthread && r > t) mb[r] = fma(Sb[r + t * LS], cf[t], mb[r]);
             const int jc = (t + 1) >> 4;
             int q = wave;
             for (int J = jc; J < jtiles; ++J)
@@ -219,9 +227,17 @@ __global__ __launch_bounds__(192) void ep_block_kernel(int n, int np, int i0, in
 #pragma unroll
                     for (int rr = 0; rr < 4; ++rr) A[(ri + fr) + (rj + fg + 4 * rr) * LS] = acc[rr];
                 }
+            __syncthreads();
+            if (tid == t + 1) {   // site t+1 starts a chunk: nothing pending on its column
+                double *pb = pub + 3 * ((t + 1) & 1);
+                pb[0] = A[(t + 1) + (t + 1) * LS];
+                pb[1] = 0.0;
+                pb[2] = mb[t + 1];
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
+    // column bsz-1 became final in the last iteration unless the block has a single site or ends on a chunk's first site
     if (rowthread) {
         if (r >= bsz) { cvec[r] = 0.0; ncoef[r] = 0.0; }
         for (int c = 0; c < GP_NB; ++c)
@@ -318,7 +334,7 @@ __global__ __launch_bounds__(1024) void ep_lml_kernel(int n, int np, const doubl
     if (threadIdx.x == 0) out[0] = red[0];
 }
 
-constexpr int EP_BLOCK_LDS = (GP_NB * (GP_NB + 1) + 5 * GP_NB + 8) * (int)sizeof(double);
+constexpr int EP_BLOCK_LDS = (GP_NB * (GP_NB + 1) + 6 * GP_NB + 16) * (int)sizeof(double);
 inline dim3 g1(int n) { return dim3((n + 255) / 256); }
 
 // end of sweep: L, Sigma, mu from the current site parameters (EpParameterEstimator.scala:56-61)
