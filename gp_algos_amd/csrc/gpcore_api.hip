@@ -1017,7 +1017,7 @@ gp_status lml_worker_eval(lml_worker &w, const double *thetas, int g, int nparam
 
 // Settings are independent and identically shaped.  They are evaluated in lockstep groups of G (one launch per algorithm
 // step for the whole group); a second worker (own context, stream and host thread) runs another group concurrently so
-// that one group's single-workgroup diagonal steps overlap the other's GEMMs.  GPCORE_LML_GROUP (default 16, capped by free
+// that one group's single-workgroup diagonal steps overlap the other's GEMMs.  GPCORE_LML_GROUP (default 32, capped by free
 // HBM) and GPCORE_LML_WORKERS (default 2) set the shape; results do not depend on either.
 extern "C" gp_status gp_lml_grad_rbf_batched(gp_ctx *ctx, const double *X, int n, int d, int ldx, const double *y, const double *thetas,
                                              int B, int nparams, double sigma_noise, double *lml, double *grad, int *info) {
@@ -1028,7 +1028,7 @@ extern "C" gp_status gp_lml_grad_rbf_batched(gp_ctx *ctx, const double *X, int n
     GP_REQUIRE(ctx, nparams >= 0 && nparams <= P && (nparams == 0 || grad), "0 <= nparams <= d+2");
     if (B == 0) return GP_OK;
     GP_HIP(ctx, hipSetDevice(ctx->device));
-    int nw = 2, G = 16;
+    int nw = 2, G = 32;
     if (const char *e = getenv("GPCORE_LML_WORKERS")) nw = atoi(e);
     if (const char *e = getenv("GPCORE_LML_GROUP")) G = atoi(e);
     G = std::max(1, std::min(G, 32));
