@@ -6,27 +6,76 @@
  *         bindings/jni/gpcore_jni.c -Lgp_algos_amd -lgpcore -o libgpcore_jni.so
  * Every function is a 1:1 forward to include/gpcore.h; all logic stays behind the C-ABI, which IS tested.
  * Breeze DenseMatrix(data, offset, majorStride) crosses as (double[] data, int offset, int ld).
- * GetPrimitiveArrayCritical is held only around the library's synchronous host<->device copies.
+ *
+ * Array discipline (SURVEY.md 8b "threading"): NO JNI critical region is ever open while the library runs.  Inputs
+ * are copied out of the Java arrays with Get<Type>ArrayRegion into malloc'd host buffers BEFORE the gpcore call,
+ * outputs are written back with Set<Type>ArrayRegion AFTER it, so kernel launches, stream synchronisation, the
+ * worker threads of the batched entry points and the multi-iteration optimiser never run with the garbage
+ * collector locked out.  Every allocation and every region copy is checked; on failure the pending Java exception
+ * (OutOfMemoryError / ArrayIndexOutOfBoundsException) is left in place and the call returns.
+ *
+ * Exceptions: GP_EINVAL -> IllegalArgumentException (require/assert in the reference), GP_ERANGE -> scala.MatchError
+ * (getAtPosition past the end), GP_ENOMEM -> OutOfMemoryError, GP_ENOTPD -> gpcore.NotPositiveDefiniteException
+ * (a RuntimeException subclass with a (String) constructor, declared in Native.scala, whose message carries the
+ * 1-based failing pivot); the Scala shim rethrows it as breeze.linalg.NotConvergedException(Iterations) -- what
+ * breeze.linalg.cholesky throws -- where scalac type-checks that constructor.
  */
 #include <jni.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include "gpcore.h"
 
 static void throw_for(JNIEnv *env, gp_ctx *ctx, gp_status st, int info) {
     const char *cls = "java/lang/RuntimeException";
-    if (st == GP_EINVAL) cls = "java/lang/IllegalArgumentException";          /* require / assert            */
-    else if (st == GP_ENOTPD) cls = "breeze/linalg/NotConvergedException";    /* what breeze.linalg.cholesky throws */
-    else if (st == GP_ERANGE) cls = "scala/MatchError";                       /* getAtPosition past the end  */
+    char msg[600];
+    if (st == GP_EINVAL) cls = "java/lang/IllegalArgumentException";
+    else if (st == GP_ENOTPD) cls = "gpcore/NotPositiveDefiniteException";
+    else if (st == GP_ERANGE) cls = "scala/MatchError";
     else if (st == GP_ENOMEM) cls = "java/lang/OutOfMemoryError";
-    (void)info;
+    snprintf(msg, sizeof msg, "%s%s (gp_status %d, info %d)", st == GP_ENOTPD ? "matrix not positive definite: " : "",
+             ctx ? gp_last_error(ctx) : "gpcore error", (int)st, info);
     jclass c = (*env)->FindClass(env, cls);
-    if (!c) c = (*env)->FindClass(env, "java/lang/RuntimeException");
-    (*env)->ThrowNew(env, c, ctx ? gp_last_error(ctx) : "gpcore error");
+    if (!c) { (*env)->ExceptionClear(env); c = (*env)->FindClass(env, "java/lang/RuntimeException"); }
+    if (c) (*env)->ThrowNew(env, c, msg);
 }
 
 #define CTX(h) ((gp_ctx *)(intptr_t)(h))
 #define MODEL(h) ((gp_model *)(intptr_t)(h))
 #define EP(h) ((gp_ep *)(intptr_t)(h))
+
+/* elements of a column-major rows x cols view with leading dimension ld */
+static jsize span(jint rows, jint cols, jint ld) { return (rows <= 0 || cols <= 0) ? 0 : (jsize)ld * (cols - 1) + rows; }
+
+/* malloc'd copy of a[off .. off+count); NULL with a pending Java exception on failure (a NULL array is an error) */
+static double *in_d(JNIEnv *env, jdoubleArray a, jsize off, jsize count) {
+    if (!a) { throw_for(env, NULL, GP_EINVAL, 0); return NULL; }
+    double *p = malloc(sizeof(double) * (size_t)(count > 0 ? count : 1));
+    if (!p) { throw_for(env, NULL, GP_ENOMEM, 0); return NULL; }
+    if (count > 0) (*env)->GetDoubleArrayRegion(env, a, off, count, p);
+    if ((*env)->ExceptionCheck(env)) { free(p); return NULL; }
+    return p;
+}
+static jint *in_i(JNIEnv *env, jintArray a, jsize count) {
+    if (!a) { throw_for(env, NULL, GP_EINVAL, 0); return NULL; }
+    jint *p = malloc(sizeof(jint) * (size_t)(count > 0 ? count : 1));
+    if (!p) { throw_for(env, NULL, GP_ENOMEM, 0); return NULL; }
+    if (count > 0) (*env)->GetIntArrayRegion(env, a, 0, count, p);
+    if ((*env)->ExceptionCheck(env)) { free(p); return NULL; }
+    return p;
+}
+/* zero-filled output staging buffer */
+static double *out_d(JNIEnv *env, jsize count) {
+    double *p = calloc((size_t)(count > 0 ? count : 1), sizeof(double));
+    if (!p) throw_for(env, NULL, GP_ENOMEM, 0);
+    return p;
+}
+static void put_d(JNIEnv *env, jdoubleArray a, jsize off, const double *p, jsize count) {
+    if (a && p && count > 0 && !(*env)->ExceptionCheck(env)) (*env)->SetDoubleArrayRegion(env, a, off, count, p);
+}
+static void put_i(JNIEnv *env, jintArray a, const jint *p, jsize count) {
+    if (a && p && count > 0 && !(*env)->ExceptionCheck(env)) (*env)->SetIntArrayRegion(env, a, 0, count, p);
+}
 
 JNIEXPORT jlong JNICALL Java_gpcore_Native_ctxCreate(JNIEnv *env, jclass k, jint device) {
     gp_ctx *ctx = NULL;
@@ -35,172 +84,263 @@ JNIEXPORT jlong JNICALL Java_gpcore_Native_ctxCreate(JNIEnv *env, jclass k, jint
     return (jlong)(intptr_t)ctx;
 }
 JNIEXPORT void JNICALL Java_gpcore_Native_ctxDestroy(JNIEnv *env, jclass k, jlong h) { gp_ctx_destroy(CTX(h)); }
-
-/* MatrixUtils.buildKernelMatrix(kernel, X) -> K (n x n, column-major) */
-JNIEXPORT void JNICALL Java_gpcore_Native_gramRbf(JNIEnv *env, jclass k, jlong h, jdoubleArray x, jint xoff, jint n, jint d,
-                                                  jint ldx, jdoubleArray theta, jdoubleArray out) {
-    double *X = (*env)->GetPrimitiveArrayCritical(env, x, NULL);
-    double *T = (*env)->GetPrimitiveArrayCritical(env, theta, NULL);
-    double *K = (*env)->GetPrimitiveArrayCritical(env, out, NULL);
-    gp_status st = gp_gram_rbf(CTX(h), X + xoff, n, d, ldx, T, K, n, GP_FULL);
-    (*env)->ReleasePrimitiveArrayCritical(env, out, K, 0);
-    (*env)->ReleasePrimitiveArrayCritical(env, theta, T, JNI_ABORT);
-    (*env)->ReleasePrimitiveArrayCritical(env, x, X, JNI_ABORT);
-    if (st != GP_OK) throw_for(env, CTX(h), st, 0);
-}
-
-/* MatrixUtils.buildMatrixWithFunc(X)(kernel.derAfterHyperParam(pos)) -> dK/dtheta_pos (n x n, column-major), pos 1-based */
-JNIEXPORT void JNICALL Java_gpcore_Native_dgramRbf(JNIEnv *env, jclass k, jlong h, jdoubleArray x, jint xoff, jint n, jint d,
-                                                   jint ldx, jdoubleArray theta, jint pos, jdoubleArray out) {
-    double *X = (*env)->GetPrimitiveArrayCritical(env, x, NULL);
-    double *T = (*env)->GetPrimitiveArrayCritical(env, theta, NULL);
-    double *D = (*env)->GetPrimitiveArrayCritical(env, out, NULL);
-    gp_status st = gp_dgram_rbf(CTX(h), X + xoff, n, d, ldx, T, pos, D, n);
-    (*env)->ReleasePrimitiveArrayCritical(env, out, D, 0);
-    (*env)->ReleasePrimitiveArrayCritical(env, theta, T, JNI_ABORT);
-    (*env)->ReleasePrimitiveArrayCritical(env, x, X, JNI_ABORT);
-    if (st != GP_OK) throw_for(env, CTX(h), st, 0);   /* GP_ERANGE -> MatchError */
-}
-
 /* releases the context's cached device workspaces (call between phases of a long-lived JVM) */
 JNIEXPORT void JNICALL Java_gpcore_Native_ctxTrim(JNIEnv *env, jclass k, jlong h) {
     gp_status st = gp_ctx_trim(CTX(h));
     if (st != GP_OK) throw_for(env, CTX(h), st, 0);
 }
 
+/* MatrixUtils.buildKernelMatrix(kernel, X) -> K (n x n, column-major) */
+JNIEXPORT void JNICALL Java_gpcore_Native_gramRbf(JNIEnv *env, jclass k, jlong h, jdoubleArray x, jint xoff, jint n, jint d,
+                                                  jint ldx, jdoubleArray theta, jdoubleArray out) {
+    double *X = in_d(env, x, xoff, span(n, d, ldx)), *T = X ? in_d(env, theta, 0, d + 2) : NULL;
+    double *K = T ? out_d(env, (jsize)n * n) : NULL;
+    if (K) {
+        gp_status st = gp_gram_rbf(CTX(h), X, n, d, ldx, T, K, n, GP_FULL);
+        if (st != GP_OK) throw_for(env, CTX(h), st, 0); else put_d(env, out, 0, K, (jsize)n * n);
+    }
+    free(K); free(T); free(X);
+}
+
+/* MatrixUtils.buildMatrixWithFunc(X)(kernel.derAfterHyperParam(pos)) -> dK/dtheta_pos (n x n), pos 1-based */
+JNIEXPORT void JNICALL Java_gpcore_Native_dgramRbf(JNIEnv *env, jclass k, jlong h, jdoubleArray x, jint xoff, jint n, jint d,
+                                                   jint ldx, jdoubleArray theta, jint pos, jdoubleArray out) {
+    double *X = in_d(env, x, xoff, span(n, d, ldx)), *T = X ? in_d(env, theta, 0, d + 2) : NULL;
+    double *D = T ? out_d(env, (jsize)n * n) : NULL;
+    if (D) {
+        gp_status st = gp_dgram_rbf(CTX(h), X, n, d, ldx, T, pos, D, n);
+        if (st != GP_OK) throw_for(env, CTX(h), st, 0); else put_d(env, out, 0, D, (jsize)n * n);   /* GP_ERANGE -> MatchError */
+    }
+    free(D); free(T); free(X);
+}
+
+/* MatrixUtils.buildKernelMatrix(kernel, X*, X) -> K* (m x n) */
+JNIEXPORT void JNICALL Java_gpcore_Native_crossGramRbf(JNIEnv *env, jclass k, jlong h, jdoubleArray xs, jint xsoff, jint m, jint ldxs,
+                                                       jdoubleArray x, jint xoff, jint n, jint ldx, jint d, jdoubleArray theta,
+                                                       jdoubleArray out) {
+    double *XS = in_d(env, xs, xsoff, span(m, d, ldxs)), *X = XS ? in_d(env, x, xoff, span(n, d, ldx)) : NULL;
+    double *T = X ? in_d(env, theta, 0, d + 2) : NULL, *K = T ? out_d(env, (jsize)m * n) : NULL;
+    if (K) {
+        gp_status st = gp_cross_gram_rbf(CTX(h), XS, m, ldxs, X, n, ldx, d, T, K, m);
+        if (st != GP_OK) throw_for(env, CTX(h), st, 0); else put_d(env, out, 0, K, (jsize)m * n);
+    }
+    free(K); free(T); free(X); free(XS);
+}
+
 /* GpPredictor.preComputeComponents -> model handle (L, alpha, LML stay in HBM) */
 JNIEXPORT jlong JNICALL Java_gpcore_Native_fitRbf(JNIEnv *env, jclass k, jlong h, jdoubleArray x, jint xoff, jint n, jint d,
                                                   jint ldx, jdoubleArray y, jdoubleArray theta, jdouble sigmaNoiseOrNaN) {
-    double *X = (*env)->GetPrimitiveArrayCritical(env, x, NULL);
-    double *Y = (*env)->GetPrimitiveArrayCritical(env, y, NULL);
-    double *T = (*env)->GetPrimitiveArrayCritical(env, theta, NULL);
+    double *X = in_d(env, x, xoff, span(n, d, ldx)), *Y = X ? in_d(env, y, 0, n) : NULL, *T = Y ? in_d(env, theta, 0, d + 2) : NULL;
     gp_model *m = NULL;
-    int info = 0;
-    gp_status st = gp_fit_rbf(CTX(h), X + xoff, n, d, ldx, Y, T, sigmaNoiseOrNaN, &m, &info);
-    (*env)->ReleasePrimitiveArrayCritical(env, theta, T, JNI_ABORT);
-    (*env)->ReleasePrimitiveArrayCritical(env, y, Y, JNI_ABORT);
-    (*env)->ReleasePrimitiveArrayCritical(env, x, X, JNI_ABORT);
-    if (st != GP_OK) { throw_for(env, CTX(h), st, info); return 0; }
+    if (T) {
+        int info = 0;
+        gp_status st = gp_fit_rbf(CTX(h), X, n, d, ldx, Y, T, sigmaNoiseOrNaN, &m, &info);
+        if (st != GP_OK) { throw_for(env, CTX(h), st, info); m = NULL; }
+    }
+    free(T); free(Y); free(X);
     return (jlong)(intptr_t)m;
 }
+/* the same for a host-built Gram matrix (any KernelFunc) */
+JNIEXPORT jlong JNICALL Java_gpcore_Native_fitFromGram(JNIEnv *env, jclass k, jlong h, jdoubleArray km, jint koff, jint n, jint ldk,
+                                                       jdoubleArray y) {
+    double *K = in_d(env, km, koff, span(n, n, ldk)), *Y = K ? in_d(env, y, 0, n) : NULL;
+    gp_model *m = NULL;
+    if (Y) {
+        int info = 0;
+        gp_status st = gp_fit_from_gram(CTX(h), K, n, ldk, Y, &m, &info);
+        if (st != GP_OK) { throw_for(env, CTX(h), st, info); m = NULL; }
+    }
+    free(Y); free(K);
+    return (jlong)(intptr_t)m;
+}
+/* what: 0 = L (count = n*n, ld = n), 1 = alpha (n), 2 = LML (1) */
 JNIEXPORT void JNICALL Java_gpcore_Native_modelGet(JNIEnv *env, jclass k, jlong h, jlong m, jint what, jdoubleArray out, jint ld) {
-    double *O = (*env)->GetPrimitiveArrayCritical(env, out, NULL);
-    gp_status st = gp_model_get(MODEL(m), what, O, ld);
-    (*env)->ReleasePrimitiveArrayCritical(env, out, O, 0);
-    if (st != GP_OK) throw_for(env, CTX(h), st, 0);
+    const jsize count = out ? (*env)->GetArrayLength(env, out) : 0;
+    double *O = out_d(env, count);
+    if (O) {
+        gp_status st = gp_model_get(MODEL(m), what, O, ld);
+        if (st != GP_OK) throw_for(env, CTX(h), st, 0); else put_d(env, out, 0, O, count);
+    }
+    free(O);
 }
 JNIEXPORT void JNICALL Java_gpcore_Native_modelDestroy(JNIEnv *env, jclass k, jlong m) { gp_model_destroy(MODEL(m)); }
 
 /* GpPredictor.predict: mean[m], var[m] (may be null), cov[m*m] (may be null) */
 JNIEXPORT void JNICALL Java_gpcore_Native_predict(JNIEnv *env, jclass k, jlong h, jlong m, jdoubleArray xs, jint xsoff, jint mm,
-                                                  jint ldxs, jdoubleArray mean, jdoubleArray var, jdoubleArray cov) {
-    double *XS = (*env)->GetPrimitiveArrayCritical(env, xs, NULL);
-    double *ME = (*env)->GetPrimitiveArrayCritical(env, mean, NULL);
-    double *VA = var ? (*env)->GetPrimitiveArrayCritical(env, var, NULL) : NULL;
-    double *CO = cov ? (*env)->GetPrimitiveArrayCritical(env, cov, NULL) : NULL;
-    gp_status st = gp_predict(MODEL(m), XS + xsoff, mm, ldxs, ME, VA, CO, mm);
-    if (cov) (*env)->ReleasePrimitiveArrayCritical(env, cov, CO, 0);
-    if (var) (*env)->ReleasePrimitiveArrayCritical(env, var, VA, 0);
-    (*env)->ReleasePrimitiveArrayCritical(env, mean, ME, 0);
-    (*env)->ReleasePrimitiveArrayCritical(env, xs, XS, JNI_ABORT);
-    if (st != GP_OK) throw_for(env, CTX(h), st, 0);
+                                                  jint d, jint ldxs, jdoubleArray mean, jdoubleArray var, jdoubleArray cov) {
+    double *XS = in_d(env, xs, xsoff, span(mm, d, ldxs));
+    double *ME = XS ? out_d(env, mm) : NULL, *VA = (ME && var) ? out_d(env, mm) : NULL, *CO = (ME && cov) ? out_d(env, (jsize)mm * mm) : NULL;
+    if (ME && (!var || VA) && (!cov || CO)) {
+        gp_status st = gp_predict(MODEL(m), XS, mm, ldxs, ME, VA, CO, mm);
+        if (st != GP_OK) throw_for(env, CTX(h), st, 0);
+        else { put_d(env, mean, 0, ME, mm); put_d(env, var, 0, VA, mm); put_d(env, cov, 0, CO, (jsize)mm * mm); }
+    }
+    free(CO); free(VA); free(ME); free(XS);
 }
 
-/* GpPredictor.logLikelihoodWithDerivatives at B settings: out = [lml_0, grad_0[0..np), lml_1, ...] */
-JNIEXPORT void JNICALL Java_gpcore_Native_lmlGradBatched(JNIEnv *env, jclass k, jlong h, jdoubleArray x, jint n, jint d, jint ldx,
-                                                         jdoubleArray y, jdoubleArray thetas, jint B, jint nparams,
+/* GpPredictor.computePosterior(trainingData, testData, l, alphaVec) with GaussianRbfKernel: mean[m], cov[m*m] or null, v[n*m] or null */
+JNIEXPORT void JNICALL Java_gpcore_Native_posteriorFromFactor(JNIEnv *env, jclass k, jlong h, jdoubleArray x, jint xoff, jint n, jint d,
+                                                              jint ldx, jdoubleArray theta, jdoubleArray l, jint loff, jint ldl,
+                                                              jdoubleArray alpha, jdoubleArray xs, jint xsoff, jint mm, jint ldxs,
+                                                              jdoubleArray mean, jdoubleArray var, jdoubleArray cov, jdoubleArray v) {
+    double *X = in_d(env, x, xoff, span(n, d, ldx)), *T = X ? in_d(env, theta, 0, d + 2) : NULL;
+    double *L = T ? in_d(env, l, loff, span(n, n, ldl)) : NULL, *A = L ? in_d(env, alpha, 0, n) : NULL;
+    double *XS = A ? in_d(env, xs, xsoff, span(mm, d, ldxs)) : NULL;
+    double *ME = XS ? out_d(env, mm) : NULL, *VA = (ME && var) ? out_d(env, mm) : NULL;
+    double *CO = (ME && cov) ? out_d(env, (jsize)mm * mm) : NULL, *V = (ME && v) ? out_d(env, (jsize)n * mm) : NULL;
+    if (ME && (!var || VA) && (!cov || CO) && (!v || V)) {
+        gp_status st = gp_posterior_from_factor(CTX(h), X, n, d, ldx, T, L, ldl, A, XS, mm, ldxs, ME, VA, CO, mm, V, n);
+        if (st != GP_OK) throw_for(env, CTX(h), st, 0);
+        else { put_d(env, mean, 0, ME, mm); put_d(env, var, 0, VA, mm); put_d(env, cov, 0, CO, (jsize)mm * mm); put_d(env, v, 0, V, (jsize)n * mm); }
+    }
+    free(V); free(CO); free(VA); free(ME); free(XS); free(A); free(L); free(T); free(X);
+}
+
+/* computePosterior with any other KernelFunc: Ks (m x n) and Kss (m x m) evaluated by the Scala loops */
+JNIEXPORT void JNICALL Java_gpcore_Native_posteriorFromGram(JNIEnv *env, jclass k, jlong h, jdoubleArray ks, jint mm, jint n,
+                                                            jdoubleArray kss, jdoubleArray l, jint loff, jint ldl, jdoubleArray alpha,
+                                                            jdoubleArray mean, jdoubleArray cov, jdoubleArray v) {
+    double *KS = in_d(env, ks, 0, (jsize)mm * n), *KSS = KS ? in_d(env, kss, 0, (jsize)mm * mm) : NULL;
+    double *L = KSS ? in_d(env, l, loff, span(n, n, ldl)) : NULL, *A = L ? in_d(env, alpha, 0, n) : NULL;
+    double *ME = A ? out_d(env, mm) : NULL, *CO = (ME && cov) ? out_d(env, (jsize)mm * mm) : NULL, *V = (ME && v) ? out_d(env, (jsize)n * mm) : NULL;
+    if (ME && (!cov || CO) && (!v || V)) {
+        gp_status st = gp_posterior_from_gram(CTX(h), KS, mm, n, mm, KSS, mm, NULL, L, ldl, A, ME, NULL, CO, mm, V, n);
+        if (st != GP_OK) throw_for(env, CTX(h), st, 0);
+        else { put_d(env, mean, 0, ME, mm); put_d(env, cov, 0, CO, (jsize)mm * mm); put_d(env, v, 0, V, (jsize)n * mm); }
+    }
+    free(V); free(CO); free(ME); free(A); free(L); free(KSS); free(KS);
+}
+
+/* GpPredictor.predict on a model fitted with fitFromGram */
+JNIEXPORT void JNICALL Java_gpcore_Native_predictFromGram(JNIEnv *env, jclass k, jlong h, jlong m, jdoubleArray ks, jint mm, jint n,
+                                                          jdoubleArray kss, jdoubleArray mean, jdoubleArray cov) {
+    double *KS = in_d(env, ks, 0, (jsize)mm * n), *KSS = KS ? in_d(env, kss, 0, (jsize)mm * mm) : NULL;
+    double *ME = KSS ? out_d(env, mm) : NULL, *CO = ME ? out_d(env, (jsize)mm * mm) : NULL;
+    if (CO) {
+        gp_status st = gp_predict_from_gram(MODEL(m), KS, mm, mm, KSS, mm, NULL, ME, NULL, CO, mm);
+        if (st != GP_OK) throw_for(env, CTX(h), st, 0);
+        else { put_d(env, mean, 0, ME, mm); put_d(env, cov, 0, CO, (jsize)mm * mm); }
+    }
+    free(CO); free(ME); free(KSS); free(KS);
+}
+
+/* GpPredictor.logLikelihoodWithDerivatives at B settings: lml[B], grad[B*nparams], info[B] */
+JNIEXPORT void JNICALL Java_gpcore_Native_lmlGradBatched(JNIEnv *env, jclass k, jlong h, jdoubleArray x, jint xoff, jint n, jint d,
+                                                         jint ldx, jdoubleArray y, jdoubleArray thetas, jint B, jint nparams,
                                                          jdouble sigmaNoiseOrNaN, jdoubleArray lml, jdoubleArray grad, jintArray info) {
-    double *X = (*env)->GetPrimitiveArrayCritical(env, x, NULL);
-    double *Y = (*env)->GetPrimitiveArrayCritical(env, y, NULL);
-    double *T = (*env)->GetPrimitiveArrayCritical(env, thetas, NULL);
-    double *L = (*env)->GetPrimitiveArrayCritical(env, lml, NULL);
-    double *G = (*env)->GetPrimitiveArrayCritical(env, grad, NULL);
-    jint *I = (*env)->GetPrimitiveArrayCritical(env, info, NULL);
-    gp_status st = gp_lml_grad_rbf_batched(CTX(h), X, n, d, ldx, Y, T, B, nparams, sigmaNoiseOrNaN, L, G, (int *)I);
-    (*env)->ReleasePrimitiveArrayCritical(env, info, I, 0);
-    (*env)->ReleasePrimitiveArrayCritical(env, grad, G, 0);
-    (*env)->ReleasePrimitiveArrayCritical(env, lml, L, 0);
-    (*env)->ReleasePrimitiveArrayCritical(env, thetas, T, JNI_ABORT);
-    (*env)->ReleasePrimitiveArrayCritical(env, y, Y, JNI_ABORT);
-    (*env)->ReleasePrimitiveArrayCritical(env, x, X, JNI_ABORT);
-    if (st != GP_OK) throw_for(env, CTX(h), st, 0);
+    double *X = in_d(env, x, xoff, span(n, d, ldx)), *Y = X ? in_d(env, y, 0, n) : NULL;
+    double *T = Y ? in_d(env, thetas, 0, (jsize)B * (d + 2)) : NULL;
+    double *L = T ? out_d(env, B) : NULL, *G = L ? out_d(env, (jsize)B * (nparams > 0 ? nparams : 1)) : NULL;
+    jint *I = G ? calloc((size_t)(B > 0 ? B : 1), sizeof(jint)) : NULL;
+    if (G && !I) throw_for(env, NULL, GP_ENOMEM, 0);
+    if (I) {
+        gp_status st = gp_lml_grad_rbf_batched(CTX(h), X, n, d, ldx, Y, T, B, nparams, sigmaNoiseOrNaN, L, G, (int *)I);
+        if (st != GP_OK) throw_for(env, CTX(h), st, 0);
+        else { put_d(env, lml, 0, L, B); put_d(env, grad, 0, G, (jsize)B * nparams); put_i(env, info, I, B); }
+    }
+    free(I); free(G); free(L); free(T); free(Y); free(X);
 }
 
 /* GpPredictor.obtainOptimalHyperParams: thetaInOut holds theta0 on entry and the best-seen point on return; returns its LML */
-JNIEXPORT jdouble JNICALL Java_gpcore_Native_optimizeRbf(JNIEnv *env, jclass k, jlong h, jdoubleArray x, jint n, jint d, jint ldx,
-                                                         jdoubleArray y, jdoubleArray thetaInOut, jint nparams, jdouble sigmaNoiseOrNaN,
-                                                         jint maxIter, jint history) {
-    double *X = (*env)->GetPrimitiveArrayCritical(env, x, NULL);
-    double *Y = (*env)->GetPrimitiveArrayCritical(env, y, NULL);
-    double *T = (*env)->GetPrimitiveArrayCritical(env, thetaInOut, NULL);
-    double theta0[66], lml = 0.0;
-    for (int i = 0; i < d + 2 && i < 66; ++i) theta0[i] = T[i];
-    gp_status st = gp_optimize_rbf(CTX(h), X, n, d, ldx, Y, theta0, nparams, sigmaNoiseOrNaN, maxIter, history, T, &lml, NULL, NULL);
-    (*env)->ReleasePrimitiveArrayCritical(env, thetaInOut, T, 0);
-    (*env)->ReleasePrimitiveArrayCritical(env, y, Y, JNI_ABORT);
-    (*env)->ReleasePrimitiveArrayCritical(env, x, X, JNI_ABORT);
-    if (st != GP_OK) throw_for(env, CTX(h), st, 0);
+JNIEXPORT jdouble JNICALL Java_gpcore_Native_optimizeRbf(JNIEnv *env, jclass k, jlong h, jdoubleArray x, jint xoff, jint n, jint d,
+                                                         jint ldx, jdoubleArray y, jdoubleArray thetaInOut, jint nparams,
+                                                         jdouble sigmaNoiseOrNaN, jint maxIter, jint history) {
+    double lml = 0.0;
+    double *X = in_d(env, x, xoff, span(n, d, ldx)), *Y = X ? in_d(env, y, 0, n) : NULL;
+    double *T0 = Y ? in_d(env, thetaInOut, 0, d + 2) : NULL, *T1 = T0 ? out_d(env, d + 2) : NULL;
+    if (T1) {
+        gp_status st = gp_optimize_rbf(CTX(h), X, n, d, ldx, Y, T0, nparams, sigmaNoiseOrNaN, maxIter, history, T1, &lml, NULL, NULL);
+        if (st != GP_OK) throw_for(env, CTX(h), st, 0); else put_d(env, thetaInOut, 0, T1, d + 2);
+    }
+    free(T1); free(T0); free(Y); free(X);
     return lml;
 }
 
 /* MeshHyperParamsLogLikelihoodEvaluator over the leaves of the grid: EP LML per setting, by setting index */
-JNIEXPORT void JNICALL Java_gpcore_Native_epLmlRbfBatched(JNIEnv *env, jclass k, jlong h, jdoubleArray x, jint n, jint d, jint ldx,
-                                                          jintArray y, jdoubleArray thetas, jint B, jdouble stopEps, jint maxSweeps,
-                                                          jboolean strict, jdoubleArray lml, jintArray sweeps, jintArray info) {
-    double *X = (*env)->GetPrimitiveArrayCritical(env, x, NULL);
-    jint *Y = (*env)->GetPrimitiveArrayCritical(env, y, NULL);
-    double *T = (*env)->GetPrimitiveArrayCritical(env, thetas, NULL);
-    double *L = (*env)->GetPrimitiveArrayCritical(env, lml, NULL);
-    jint *S = (*env)->GetPrimitiveArrayCritical(env, sweeps, NULL);
-    jint *I = (*env)->GetPrimitiveArrayCritical(env, info, NULL);
-    gp_status st = gp_ep_lml_rbf_batched(CTX(h), X, n, d, ldx, (const int32_t *)Y, T, B, stopEps, maxSweeps, strict ? 1 : 0, L, (int *)S, (int *)I);
-    (*env)->ReleasePrimitiveArrayCritical(env, info, I, 0);
-    (*env)->ReleasePrimitiveArrayCritical(env, sweeps, S, 0);
-    (*env)->ReleasePrimitiveArrayCritical(env, lml, L, 0);
-    (*env)->ReleasePrimitiveArrayCritical(env, thetas, T, JNI_ABORT);
-    (*env)->ReleasePrimitiveArrayCritical(env, y, Y, JNI_ABORT);
-    (*env)->ReleasePrimitiveArrayCritical(env, x, X, JNI_ABORT);
-    if (st != GP_OK) throw_for(env, CTX(h), st, 0);
+JNIEXPORT void JNICALL Java_gpcore_Native_epLmlRbfBatched(JNIEnv *env, jclass k, jlong h, jdoubleArray x, jint xoff, jint n, jint d,
+                                                          jint ldx, jintArray y, jdoubleArray thetas, jint B, jdouble stopEps,
+                                                          jint maxSweeps, jboolean strict, jdoubleArray lml, jintArray sweeps,
+                                                          jintArray info) {
+    double *X = in_d(env, x, xoff, span(n, d, ldx));
+    jint *Y = X ? in_i(env, y, n) : NULL;
+    double *T = Y ? in_d(env, thetas, 0, (jsize)B * (d + 2)) : NULL, *L = T ? out_d(env, B) : NULL;
+    jint *S = L ? calloc((size_t)(B > 0 ? B : 1), sizeof(jint)) : NULL, *I = S ? calloc((size_t)(B > 0 ? B : 1), sizeof(jint)) : NULL;
+    if (L && !I) throw_for(env, NULL, GP_ENOMEM, 0);
+    if (I) {
+        gp_status st = gp_ep_lml_rbf_batched(CTX(h), X, n, d, ldx, (const int32_t *)Y, T, B, stopEps, maxSweeps, strict ? 1 : 0, L,
+                                             (int *)S, (int *)I);
+        if (st != GP_OK) throw_for(env, CTX(h), st, 0);
+        else { put_d(env, lml, 0, L, B); put_i(env, sweeps, S, B); put_i(env, info, I, B); }
+    }
+    free(I); free(S); free(L); free(T); free(Y); free(X);
 }
 
-/* breeze.linalg.cholesky / MatrixUtils.forwardSolve, backSolve, invTriangular */
+/* breeze.linalg.cholesky: a (n x n at off, ld lda) is replaced by L */
 JNIEXPORT void JNICALL Java_gpcore_Native_potrfLower(JNIEnv *env, jclass k, jlong h, jdoubleArray a, jint off, jint n, jint lda) {
-    double *A = (*env)->GetPrimitiveArrayCritical(env, a, NULL);
-    int info = 0;
-    gp_status st = gp_potrf_lower(CTX(h), A + off, n, lda, &info);
-    (*env)->ReleasePrimitiveArrayCritical(env, a, A, 0);
-    if (st != GP_OK) throw_for(env, CTX(h), st, info);
+    const jsize cnt = span(n, n, lda);
+    double *A = in_d(env, a, off, cnt);
+    if (A) {
+        int info = 0;
+        gp_status st = gp_potrf_lower(CTX(h), A, n, lda, &info);
+        if (st != GP_OK) throw_for(env, CTX(h), st, info); else put_d(env, a, off, A, cnt);
+    }
+    free(A);
 }
+/* MatrixUtils.forwardSolve (trans = 0) / backSolve(L.t, .) (trans = 1): b (n x nrhs) is replaced by the solution */
 JNIEXPORT void JNICALL Java_gpcore_Native_trsmLower(JNIEnv *env, jclass k, jlong h, jint trans, jdoubleArray l, jint loff, jint n,
                                                     jint ldl, jdoubleArray b, jint boff, jint nrhs, jint ldb) {
-    double *L = (*env)->GetPrimitiveArrayCritical(env, l, NULL);
-    double *B = (*env)->GetPrimitiveArrayCritical(env, b, NULL);
-    gp_status st = gp_trsm_lower(CTX(h), trans, L + loff, n, ldl, B + boff, nrhs, ldb);
-    (*env)->ReleasePrimitiveArrayCritical(env, b, B, 0);
-    (*env)->ReleasePrimitiveArrayCritical(env, l, L, JNI_ABORT);
-    if (st != GP_OK) throw_for(env, CTX(h), st, 0);
+    const jsize cnt = span(n, nrhs, ldb);
+    double *L = in_d(env, l, loff, span(n, n, ldl)), *B = L ? in_d(env, b, boff, cnt) : NULL;
+    if (B) {
+        gp_status st = gp_trsm_lower(CTX(h), trans, L, n, ldl, B, nrhs, ldb);
+        if (st != GP_OK) throw_for(env, CTX(h), st, 0); else put_d(env, b, boff, B, cnt);
+    }
+    free(B); free(L);
+}
+/* MatrixUtils.invTriangular(L, isUpper = false) */
+JNIEXPORT void JNICALL Java_gpcore_Native_invLower(JNIEnv *env, jclass k, jlong h, jdoubleArray l, jint loff, jint n, jint ldl,
+                                                   jdoubleArray out) {
+    double *L = in_d(env, l, loff, span(n, n, ldl)), *O = L ? out_d(env, (jsize)n * n) : NULL;
+    if (O) {
+        gp_status st = gp_inv_lower(CTX(h), L, n, ldl, O, n);
+        if (st != GP_OK) throw_for(env, CTX(h), st, 0); else put_d(env, out, 0, O, (jsize)n * n);
+    }
+    free(O); free(L);
 }
 
 /* EpParameterEstimator / GpClassifier */
 JNIEXPORT jlong JNICALL Java_gpcore_Native_epCreate(JNIEnv *env, jclass k, jlong h, jdoubleArray km, jint off, jint n, jint ldk,
                                                     jintArray targets) {
-    double *K = (*env)->GetPrimitiveArrayCritical(env, km, NULL);
-    jint *Y = (*env)->GetPrimitiveArrayCritical(env, targets, NULL);
+    double *K = in_d(env, km, off, span(n, n, ldk));
+    jint *Y = K ? in_i(env, targets, n) : NULL;
     gp_ep *ep = NULL;
-    gp_status st = gp_ep_create(CTX(h), K + off, n, ldk, (const int32_t *)Y, &ep);
-    (*env)->ReleasePrimitiveArrayCritical(env, targets, Y, JNI_ABORT);
-    (*env)->ReleasePrimitiveArrayCritical(env, km, K, JNI_ABORT);
-    if (st != GP_OK) { throw_for(env, CTX(h), st, 0); return 0; }
+    if (Y) {
+        gp_status st = gp_ep_create(CTX(h), K, n, ldk, (const int32_t *)Y, &ep);
+        if (st != GP_OK) { throw_for(env, CTX(h), st, 0); ep = NULL; }
+    }
+    free(Y); free(K);
     return (jlong)(intptr_t)ep;
 }
-JNIEXPORT void JNICALL Java_gpcore_Native_epSweep(JNIEnv *env, jclass k, jlong h, jlong e, jint nsweeps, jdoubleArray tau, jdoubleArray nu) {
-    double *T = (*env)->GetPrimitiveArrayCritical(env, tau, NULL);
-    double *N = (*env)->GetPrimitiveArrayCritical(env, nu, NULL);
-    int info = 0;
-    gp_status st = gp_ep_sweep(EP(e), nsweeps, T, N, &info);
-    (*env)->ReleasePrimitiveArrayCritical(env, nu, N, 0);
-    (*env)->ReleasePrimitiveArrayCritical(env, tau, T, 0);
-    if (st != GP_OK) throw_for(env, CTX(h), st, info);
+JNIEXPORT void JNICALL Java_gpcore_Native_epSweep(JNIEnv *env, jclass k, jlong h, jlong e, jint nsweeps, jint n, jdoubleArray tau,
+                                                  jdoubleArray nu) {
+    double *T = out_d(env, n), *N = T ? out_d(env, n) : NULL;
+    if (N) {
+        int info = 0;
+        gp_status st = gp_ep_sweep(EP(e), nsweeps, T, N, &info);
+        if (st != GP_OK) throw_for(env, CTX(h), st, info); else { put_d(env, tau, 0, T, n); put_d(env, nu, 0, N, n); }
+    }
+    free(N); free(T);
+}
+/* learnParams = Some(siteParams, _): load site parameters estimated earlier */
+JNIEXPORT void JNICALL Java_gpcore_Native_epSetSiteParams(JNIEnv *env, jclass k, jlong h, jlong e, jint n, jdoubleArray tau,
+                                                          jdoubleArray nu) {
+    double *T = in_d(env, tau, 0, n), *N = T ? in_d(env, nu, 0, n) : NULL;
+    if (N) {
+        int info = 0;
+        gp_status st = gp_ep_set_site_params(EP(e), T, N, &info);
+        if (st != GP_OK) throw_for(env, CTX(h), st, info);
+    }
+    free(N); free(T);
 }
 JNIEXPORT jdouble JNICALL Java_gpcore_Native_epLml(JNIEnv *env, jclass k, jlong h, jlong e, jboolean strict) {
     double v = 0.0;
@@ -208,21 +348,33 @@ JNIEXPORT jdouble JNICALL Java_gpcore_Native_epLml(JNIEnv *env, jclass k, jlong 
     if (st != GP_OK) throw_for(env, CTX(h), st, 0);
     return v;
 }
-JNIEXPORT void JNICALL Java_gpcore_Native_epGet(JNIEnv *env, jclass k, jlong h, jlong e, jint what, jdoubleArray out, jint ld) {
-    double *O = (*env)->GetPrimitiveArrayCritical(env, out, NULL);
-    gp_status st = gp_ep_get(EP(e), what, O, ld);
-    (*env)->ReleasePrimitiveArrayCritical(env, out, O, 0);
-    if (st != GP_OK) throw_for(env, CTX(h), st, 0);
+/* MarginalLikelihoodEvaluator.logLikelihoodDerivativesAfterHyperParams: grad[d+2] */
+JNIEXPORT void JNICALL Java_gpcore_Native_epLmlGradRbf(JNIEnv *env, jclass k, jlong h, jlong e, jdoubleArray x, jint xoff, jint n,
+                                                       jint d, jint ldx, jdoubleArray theta, jboolean strict, jdoubleArray grad) {
+    double *X = in_d(env, x, xoff, span(n, d, ldx)), *T = X ? in_d(env, theta, 0, d + 2) : NULL, *G = T ? out_d(env, d + 2) : NULL;
+    if (G) {
+        gp_status st = gp_ep_lml_grad_rbf(EP(e), X, d, ldx, T, strict ? 1 : 0, G);
+        if (st != GP_OK) throw_for(env, CTX(h), st, 0); else put_d(env, grad, 0, G, d + 2);
+    }
+    free(G); free(T); free(X);
 }
-JNIEXPORT void JNICALL Java_gpcore_Native_epPredict(JNIEnv *env, jclass k, jlong h, jlong e, jdoubleArray ks, jint off, jint m, jint ldks,
-                                                    jdoubleArray kssDiag, jdoubleArray prob) {
-    double *KS = (*env)->GetPrimitiveArrayCritical(env, ks, NULL);
-    double *KD = (*env)->GetPrimitiveArrayCritical(env, kssDiag, NULL);
-    double *P = (*env)->GetPrimitiveArrayCritical(env, prob, NULL);
-    gp_status st = gp_ep_predict(EP(e), KS + off, m, ldks, KD, P);
-    (*env)->ReleasePrimitiveArrayCritical(env, prob, P, 0);
-    (*env)->ReleasePrimitiveArrayCritical(env, kssDiag, KD, JNI_ABORT);
-    (*env)->ReleasePrimitiveArrayCritical(env, ks, KS, JNI_ABORT);
-    if (st != GP_OK) throw_for(env, CTX(h), st, 0);
+/* what: 0 = L, 1 = Sigma (n*n, ld), 2 = mu, 3 = cavity tau, 4 = cavity nu (n) */
+JNIEXPORT void JNICALL Java_gpcore_Native_epGet(JNIEnv *env, jclass k, jlong h, jlong e, jint what, jdoubleArray out, jint ld) {
+    const jsize count = out ? (*env)->GetArrayLength(env, out) : 0;
+    double *O = out_d(env, count);
+    if (O) {
+        gp_status st = gp_ep_get(EP(e), what, O, ld);
+        if (st != GP_OK) throw_for(env, CTX(h), st, 0); else put_d(env, out, 0, O, count);
+    }
+    free(O);
+}
+JNIEXPORT void JNICALL Java_gpcore_Native_epPredict(JNIEnv *env, jclass k, jlong h, jlong e, jdoubleArray ks, jint off, jint m, jint n,
+                                                    jint ldks, jdoubleArray kssDiag, jdoubleArray prob) {
+    double *KS = in_d(env, ks, off, span(m, n, ldks)), *KD = KS ? in_d(env, kssDiag, 0, m) : NULL, *P = KD ? out_d(env, m) : NULL;
+    if (P) {
+        gp_status st = gp_ep_predict(EP(e), KS, m, ldks, KD, P);
+        if (st != GP_OK) throw_for(env, CTX(h), st, 0); else put_d(env, prob, 0, P, m);
+    }
+    free(P); free(KD); free(KS);
 }
 JNIEXPORT void JNICALL Java_gpcore_Native_epDestroy(JNIEnv *env, jclass k, jlong e) { gp_ep_destroy(EP(e)); }

@@ -3,68 +3,141 @@ package gp.regression
 import breeze.linalg.{DenseMatrix, DenseVector}
 import gpcore.Native
 import utils.KernelRequisites.{GaussianRbfKernel, KernelFunc, KernelFuncHyperParams}
+import utils.MatrixUtils
 import utils.StatsUtils.GaussianDistribution
 
-/** Drop-in body for gp.regression.GpPredictor: same constructor and method signatures as the reference class,
-  * numerics in libgpcore.so.  A GaussianRbfKernel goes to the fused device path; any other KernelFunc keeps the
-  * reference's Scala loops for the Gram matrix and hands it over through gp_fit_from_gram (not shown). */
+/** Drop-in body for gp.regression.GpPredictor (gp/regression/GpPredictor.scala:15-150): same constructor and method
+  * signatures, numerics in libgpcore.so.  A GaussianRbfKernel goes to the fused device path; any other KernelFunc keeps the
+  * reference's Scala loops for the Gram matrices (MatrixUtils.buildKernelMatrix) and hands them to gp_fit_from_gram /
+  * gp_predict_from_gram / gp_posterior_from_gram, so the O(n^3) and O(n^2 m) work still runs on the GPU. */
 class GpPredictor(val kernelFunc: KernelFunc) {
   import GpPredictor._
+  import Native.{defaultCtx => ctx, dense, rethrowNotPd}
 
-  private def compact(m: DenseMatrix[Double]): DenseMatrix[Double] =
-    if (m.isTranspose || m.majorStride != m.rows) m.copy else m      // views cross the API (GpPredictorTest.scala:66)
+  private def isRbf(k: KernelFunc) = k.isInstanceOf[GaussianRbfKernel]
 
   private def withModel[T](x: DenseMatrix[Double], hp: KernelFuncHyperParams, sigmaNoise: Option[Double],
-                           targets: DenseVector[Double])(body: Long => T): T = {
+                           targets: DenseVector[Double])(body: (Long, KernelFunc) => T): T = {
     require(x.rows == targets.length, "Number of objects in training data matrix should be equal to targets vector length")
-    val xc = compact(x)
-    val model = Native.fitRbf(Native.defaultCtx, xc.data, xc.offset, xc.rows, xc.cols, xc.majorStride,
-      targets.toArray, hp.toDenseVector.toArray, sigmaNoise.getOrElse(Double.NaN))
-    try body(model) finally Native.modelDestroy(model)
+    val kf = kernelFunc.changeHyperParams(hp.toDenseVector)
+    val model = rethrowNotPd {
+      if (isRbf(kf)) {
+        val xc = dense(x)   // views cross the API (GpPredictorTest.scala:66): offset and majorStride are passed through
+        Native.fitRbf(ctx, xc.data, xc.offset, xc.rows, xc.cols, xc.majorStride, targets.toArray, hp.toDenseVector.toArray,
+          sigmaNoise.getOrElse(Double.NaN))
+      } else {
+        val k = MatrixUtils.buildKernelMatrix(kf, x)
+        sigmaNoise.foreach(v => (0 until k.rows).foreach(i => k(i, i) += v))      // un-squared, GpPredictor.scala:116
+        Native.fitFromGram(ctx, k.data, k.offset, k.rows, k.majorStride, targets.toArray)
+      }
+    }
+    try body(model, kf) finally Native.modelDestroy(model)
   }
+
+  def preComputeComponents(trainingData: DenseMatrix[Double], sigmaNoise: Option[Double], targets: DenseVector[Double]): afterLearningComponents =
+    preComputeComponents(trainingData, kernelFunc.hyperParams, sigmaNoise, targets)
 
   def preComputeComponents(trainingData: DenseMatrix[Double], hyperParams: KernelFuncHyperParams,
                            sigmaNoise: Option[Double], targets: DenseVector[Double]): afterLearningComponents =
-    withModel(trainingData, hyperParams, sigmaNoise, targets) { model =>
+    withModel(trainingData, hyperParams, sigmaNoise, targets) { (model, _) =>
       val n = trainingData.rows
       val l = new Array[Double](n * n); val alpha = new Array[Double](n)
-      Native.modelGet(Native.defaultCtx, model, 0, l, n)
-      Native.modelGet(Native.defaultCtx, model, 1, alpha, n)
+      Native.modelGet(ctx, model, 0, l, n)
+      Native.modelGet(ctx, model, 1, alpha, n)
       (new DenseMatrix(n, n, l), DenseVector(alpha), sigmaNoise.map(v => DenseMatrix.eye[Double](n) :* v))
     }
 
   def predict(input: PredictionInput, hyperParams: KernelFuncHyperParams = kernelFunc.hyperParams): (GaussianDistribution, Double) =
-    withModel(input.trainingData, hyperParams, input.sigmaNoise, input.targets) { model =>
-      val xs = compact(input.testData); val m = xs.rows
+    withModel(input.trainingData, hyperParams, input.sigmaNoise, input.targets) { (model, kf) =>
+      val m = input.testData.rows; val n = input.trainingData.rows
       val mean = new Array[Double](m); val cov = new Array[Double](m * m); val lml = new Array[Double](1)
-      Native.predict(Native.defaultCtx, model, xs.data, xs.offset, m, xs.majorStride, mean, null, cov)
-      Native.modelGet(Native.defaultCtx, model, 2, lml, 1)
-      (GaussianDistribution(mean = DenseVector(mean), sigma = new DenseMatrix(m, m, cov)), lml(0))
+      if (isRbf(kf)) {
+        val xs = dense(input.testData)
+        Native.predict(ctx, model, xs.data, xs.offset, m, xs.cols, xs.majorStride, mean, null, cov)
+      } else {
+        val ks = MatrixUtils.buildKernelMatrix(kf, input.testData, input.trainingData)
+        val kss = MatrixUtils.buildKernelMatrix(kf, input.testData)
+        Native.predictFromGram(ctx, model, ks.data, m, n, kss.data, mean, cov)
+      }
+      Native.modelGet(ctx, model, 2, lml, 1)
+      val fVariance = new DenseMatrix(m, m, cov)
+      // GpPredictor.scala:37-39: `fVariance + noiseDiagMtx.get` adds the n x n noise matrix to the m x m covariance, so
+      // with sigmaNoise = Some(_) the reference only works for m == n; Breeze's own dimension check is kept by doing the
+      // same addition
+      val withNoise = input.sigmaNoise match {
+        case Some(v) => fVariance + (DenseMatrix.eye[Double](n) :* v)
+        case None => fVariance
+      }
+      (GaussianDistribution(mean = DenseVector(mean), sigma = withNoise), lml(0))
     }
+
+  def computePosterior(trainingData: DenseMatrix[Double], testData: DenseMatrix[Double], l: DenseMatrix[Double],
+                       alphaVec: DenseVector[Double]): (GaussianDistribution, DenseMatrix[Double]) =
+    computePosterior(trainingData, testData, l, alphaVec, kernelFunc)
+
+  // GpPredictor.scala:50-58 -- the entry GPOptimizer.scala:91 and GPUnscentedKalmanFilter.scala:78-87,141-142 call
+  def computePosterior(trainingData: DenseMatrix[Double], testData: DenseMatrix[Double], l: DenseMatrix[Double],
+                       alphaVec: DenseVector[Double], kernelFunc: KernelFunc): (GaussianDistribution, DenseMatrix[Double]) = {
+    val n = trainingData.rows; val m = testData.rows
+    val mean = new Array[Double](m); val cov = new Array[Double](m * m); val v = new Array[Double](n * m)
+    val lc = dense(l)
+    kernelFunc match {
+      case rbf: GaussianRbfKernel =>
+        val x = dense(trainingData); val xs = dense(testData)
+        Native.posteriorFromFactor(ctx, x.data, x.offset, n, x.cols, x.majorStride, rbf.hyperParams.toDenseVector.toArray,
+          lc.data, lc.offset, lc.majorStride, alphaVec.toArray, xs.data, xs.offset, m, xs.majorStride, mean, null, cov, v)
+      case other =>
+        val ks = MatrixUtils.buildKernelMatrix(other, testData, trainingData)
+        val kss = MatrixUtils.buildKernelMatrix(other, testData)
+        Native.posteriorFromGram(ctx, ks.data, m, n, kss.data, lc.data, lc.offset, lc.majorStride, alphaVec.toArray, mean, cov, v)
+    }
+    (GaussianDistribution(mean = DenseVector(mean), sigma = new DenseMatrix(m, m, cov)), new DenseMatrix(n, m, v))
+  }
 
   def logLikelihoodWithDerivatives(input: PredictionTrainingInput, hyperParams: KernelFuncHyperParams,
                                    optimizedParamsNum: Int): (Double, DenseVector[Double]) = {
-    val x = compact(input.trainingData)
+    require(isRbf(kernelFunc), "device LML gradient is implemented for GaussianRbfKernel")
+    val x = dense(input.trainingData)
     val lml = new Array[Double](1); val grad = new Array[Double](optimizedParamsNum); val info = new Array[Int](1)
-    Native.lmlGradBatched(Native.defaultCtx, x.data, x.rows, x.cols, x.majorStride, input.targets.toArray,
+    Native.lmlGradBatched(ctx, x.data, x.offset, x.rows, x.cols, x.majorStride, input.targets.toArray,
       hyperParams.toDenseVector.toArray, 1, optimizedParamsNum, input.sigmaNoise.getOrElse(Double.NaN), lml, grad, info)
+    if (info(0) != 0)   // breeze.linalg.cholesky throws inside preComputeComponents (GpPredictor.scala:63-64,120)
+      throw new breeze.linalg.NotConvergedException(breeze.linalg.NotConvergedException.Iterations,
+        "matrix not positive definite at pivot " + info(0))
     (lml(0), DenseVector(grad))
   }
 
   // GpPredictor.scala:126-142 -- BreezeLbfgsOptimizer(maxIter = 20), m = 4, best-seen point; optimizeNoise = false keeps sn fixed
   def obtainOptimalHyperParams(trainingData: DenseMatrix[Double], sigmaNoise: Option[Double], targets: DenseVector[Double],
                                optimizeNoise: Boolean): KernelFuncHyperParams = {
-    val x = compact(trainingData)
+    val x = dense(trainingData)
     val theta = kernelFunc.hyperParams.toDenseVector.toArray
-    Native.optimizeRbf(Native.defaultCtx, x.data, x.rows, x.cols, x.majorStride, targets.toArray, theta,
-      if (optimizeNoise) theta.length else theta.length - 1, sigmaNoise.getOrElse(Double.NaN), 20, 4)
+    rethrowNotPd {
+      Native.optimizeRbf(ctx, x.data, x.offset, x.rows, x.cols, x.majorStride, targets.toArray, theta,
+        if (optimizeNoise) theta.length else theta.length - 1, sigmaNoise.getOrElse(Double.NaN), 20, 4)
+    }
     kernelFunc.hyperParams.fromDenseVector(DenseVector(theta))
+  }
+
+  def predictWithParamsOptimization(input: PredictionInput, optimizeNoise: Boolean): (GaussianDistribution, Double, KernelFuncHyperParams) = {
+    val hp = obtainOptimalHyperParams(input.trainingData, input.sigmaNoise, input.targets, optimizeNoise)
+    val (dist, ll) = predict(input, hyperParams = hp)
+    (dist, ll, hp)
+  }
+
+  def preComputeComponentsWithHpOptimization(trainingData: DenseMatrix[Double], sigmaNoise: Option[Double],
+                                             targets: DenseVector[Double]): (afterLearningComponents, KernelFuncHyperParams) = {
+    val hp = obtainOptimalHyperParams(trainingData, sigmaNoise, targets, true)
+    (preComputeComponents(trainingData, hp, sigmaNoise, targets), hp)
   }
 }
 
 object GpPredictor {
   type afterLearningComponents = (DenseMatrix[Double], DenseVector[Double], Option[DenseMatrix[Double]])
   case class PredictionInput(trainingData: DenseMatrix[Double], testData: DenseMatrix[Double],
-                             sigmaNoise: Option[Double], targets: DenseVector[Double])
+                             sigmaNoise: Option[Double], targets: DenseVector[Double]) {
+    def toPredictionTrainingInput: PredictionTrainingInput =
+      PredictionTrainingInput(trainingData = trainingData, sigmaNoise = sigmaNoise, targets = targets)
+  }
   case class PredictionTrainingInput(trainingData: DenseMatrix[Double], sigmaNoise: Option[Double], targets: DenseVector[Double])
 }

@@ -52,6 +52,9 @@ SIGNATURES = {
     "gp_model_destroy": (None, [_vp]),
     "gp_predict": (_i, [_vp, _dp, _i, _i, _dp, _dp, _dp, _i]),
     "gp_predict_dev": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "gp_posterior_from_factor": (_i, [_vp, _dp, _i, _i, _i, _dp, _dp, _i, _dp, _dp, _i, _i, _dp, _dp, _dp, _i, _dp, _i]),
+    "gp_posterior_from_gram": (_i, [_vp, _dp, _i, _i, _i, _dp, _i, _dp, _dp, _i, _dp, _dp, _dp, _dp, _i, _dp, _i]),
+    "gp_predict_from_gram": (_i, [_vp, _dp, _i, _i, _dp, _i, _dp, _dp, _dp, _dp, _i]),
     "gp_lml_grad_rbf_batched": (_i, [_vp, _dp, _i, _i, _i, _dp, _dp, _i, _i, _d, _dp, _dp, _ip]),
     "gp_optimize_rbf": (_i, [_vp, _dp, _i, _i, _i, _dp, _dp, _i, _d, _i, _i, _dp, _dp, _ip, _ip]),
     "gp_ep_create": (_i, [_vp, _dp, _i, _i, C.POINTER(C.c_int32), C.POINTER(_vp)]),

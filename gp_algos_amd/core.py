@@ -145,6 +145,41 @@ class Context:
         self.check(self._lib.gp_inv_lower(self.h, L.dptr(Lm), n, max(n, 1), L.dptr(out), max(n, 1)))
         return out
 
+    def posterior_from_factor(self, X, theta, Lm, alpha, Xs, full_cov=False, want_v=False):
+        """gp_posterior_from_factor (GpPredictor.computePosterior with the ARD-RBF kernel): (mean, var, cov|None, V|None)."""
+        X, theta, Lm, alpha, Xs = L.f64(X), L.f64(theta), L.f64(Lm), L.f64(alpha), L.f64(Xs)
+        n, d = X.shape
+        m = Xs.shape[0]
+        if Xs.shape[1] != d or theta.size != d + 2 or Lm.shape != (n, n) or alpha.size != n:
+            raise ValueError("dimension mismatch")
+        mean, var = np.zeros(m), np.zeros(m)
+        cov = np.zeros((m, m), order="F") if full_cov else None
+        V = np.zeros((n, m), order="F") if want_v else None
+        self.check(self._lib.gp_posterior_from_factor(self.h, L.dptr(X), n, d, max(n, 1), L.dptr(theta), L.dptr(Lm), max(n, 1), L.dptr(alpha),
+                                                      L.dptr(Xs), m, max(m, 1), L.dptr(mean), L.dptr(var),
+                                                      L.dptr(cov) if full_cov else None, max(m, 1), L.dptr(V) if want_v else None, max(n, 1)))
+        return mean, var, cov, V
+
+    def posterior_from_gram(self, Ks, Lm, alpha, Kss=None, kss_diag=None, want_v=False):
+        """gp_posterior_from_gram (computePosterior with a host-evaluated KernelFunc): (mean, var|None, cov|None, V|None)."""
+        Ks, Lm, alpha = L.f64(Ks), L.f64(Lm), L.f64(alpha)
+        m, n = Ks.shape
+        if Lm.shape != (n, n) or alpha.size != n:
+            raise ValueError("dimension mismatch")
+        Kss = None if Kss is None else L.f64(Kss)
+        kd = None if kss_diag is None else L.f64(kss_diag)
+        if (Kss is not None and Kss.shape != (m, m)) or (kd is not None and kd.size != m):
+            raise ValueError("dimension mismatch")
+        mean = np.zeros(m)
+        var = np.zeros(m) if (Kss is not None or kd is not None) else None
+        cov = np.zeros((m, m), order="F") if Kss is not None else None
+        V = np.zeros((n, m), order="F") if want_v else None
+        self.check(self._lib.gp_posterior_from_gram(self.h, L.dptr(Ks), m, n, max(m, 1), L.dptr(Kss) if Kss is not None else None, max(m, 1),
+                                                    L.dptr(kd) if kd is not None else None, L.dptr(Lm), max(n, 1), L.dptr(alpha), L.dptr(mean),
+                                                    L.dptr(var) if var is not None else None, L.dptr(cov) if cov is not None else None,
+                                                    max(m, 1), L.dptr(V) if want_v else None, max(n, 1)))
+        return mean, var, cov, V
+
     def lml_grad_batched(self, X, y, thetas, nparams=None, sigma_noise=None):
         X, y = L.f64(X), L.f64(y)
         n, d = X.shape
@@ -250,6 +285,26 @@ class RegressionModel:
         cov = np.zeros((m, m), order="F") if full_cov else None
         self.ctx.check(self.ctx._lib.gp_predict(self.h, L.dptr(Xs), m, max(m, 1), L.dptr(mean), L.dptr(var),
                                                 L.dptr(cov) if full_cov else None, max(m, 1)))
+        return mean, var, cov
+
+
+    def predict_from_gram(self, Ks, Kss=None, kss_diag=None):
+        """gp_predict_from_gram: posterior for a model fitted from a host-built Gram matrix; (mean, var|None, cov|None)."""
+        Ks = L.f64(Ks)
+        m = Ks.shape[0]
+        if Ks.shape[1] != self.n:
+            raise ValueError("test-train matrix must be m x n")
+        Kss = None if Kss is None else L.f64(Kss)
+        kd = None if kss_diag is None else L.f64(kss_diag)
+        if (Kss is not None and Kss.shape != (m, m)) or (kd is not None and kd.size != m):
+            raise ValueError("dimension mismatch")
+        mean = np.zeros(m)
+        var = np.zeros(m) if (Kss is not None or kd is not None) else None
+        cov = np.zeros((m, m), order="F") if Kss is not None else None
+        self.ctx.check(self.ctx._lib.gp_predict_from_gram(self.h, L.dptr(Ks), m, max(m, 1), L.dptr(Kss) if Kss is not None else None, max(m, 1),
+                                                          L.dptr(kd) if kd is not None else None, L.dptr(mean),
+                                                          L.dptr(var) if var is not None else None, L.dptr(cov) if cov is not None else None,
+                                                          max(m, 1)))
         return mean, var, cov
 
 

@@ -106,7 +106,7 @@ void chol_blocked(gp_ctx *ctx, double *A, int np, int lda, double *dinv, int ext
     const bool lookahead = ctx->lookahead && count == 1;
     bool side_busy = false;
     // outer panel width: 512 (K = 512 trailing updates); 1024 measured 3 % faster at n = 32768 (205 -> 198.5 ms), equal at 8192
-    static const int outer_env = [] { const char *e = getenv("GPCORE_OUTER"); int v = e ? atoi(e) : 0; return (v >= GP_NB && v % GP_NB == 0) ? v : 0; }();
+    const int outer_env = gp_env_blocks("GPCORE_OUTER");
     const int OUTER = outer_env ? outer_env : (np > 16384 ? 2 * GP_OUTER : GP_OUTER);
     for (int K0 = 0; K0 < np; K0 += OUTER) {
         const int wcols = std::min(OUTER, np - K0);
@@ -164,8 +164,9 @@ void back_solve_vec(gp_ctx *ctx, const double *L, int np, int ldl, const double 
 // sumsq (length mp) accumulates row sums of squares of the result when non-null.
 // Row count (in 128-row tiles) from which the left-looking form is used
 int rows_left_min() {
-    static const int v = [] { const char *e = getenv("GPCORE_ROWS_LEFT_MIN"); int x = e ? atoi(e) : 0; return x > 0 ? x : 192; }();
-    return v;
+    const char *e = getenv("GPCORE_ROWS_LEFT_MIN");   // read per call: the tests lower it to run the large-batch form at small sizes
+    const int x = e ? atoi(e) : 0;
+    return x > 0 ? x : 192;
 }
 
 // Lw (np x np, lower, ld np): block row i = L_ii^-1 [ -L_i,<i | I ].  With it the left-looking step for block column i,
@@ -210,7 +211,7 @@ void solve_rows_lower(gp_ctx *ctx, double *Vt, int mp, const double *L, int np, 
     if (right_looking) {
         // two-level: inside an outer block of OB columns the K = 128 updates touch only that block's later columns; everything
         // to the right of the block is updated once per outer block with K = OB (fewer passes over the later columns of Vt)
-        static const int ob_env = [] { const char *e = getenv("GPCORE_ROWS_OUTER"); int v = e ? atoi(e) : 0; return (v >= GP_NB && v % GP_NB == 0) ? v : 0; }();
+        const int ob_env = gp_env_blocks("GPCORE_ROWS_OUTER");
         const int OB = ob_env ? ob_env : 2 * GP_OUTER;   // 1024: measured +1.4 % on the EP refactorisation (n = 4096) over 128, 512 in between
         for (int c0 = 0; c0 < np; c0 += OB) {
             const int c1 = std::min(np, c0 + OB);
@@ -268,7 +269,7 @@ void inverse_transpose_lower(gp_ctx *ctx, double *T, const double *L, int np, in
     bgemm.s0 = strideT, bgemm.s1 = strideL, bgemm.s2 = strideT;
     // Outer block width OB: inside an outer block column the K = 128 updates touch only that block's own columns; everything
     // to the right of it is updated once per outer block with K = OB.  OB = 128 is the plain right-looking form.
-    static const int ob_env = [] { const char *e = getenv("GPCORE_TINV_OUTER"); int v = e ? atoi(e) : 0; return (v >= GP_NB && v % GP_NB == 0) ? v : 0; }();
+    const int ob_env = gp_env_blocks("GPCORE_TINV_OUTER");
     const int OB = ob_env ? ob_env : (count >= 4 ? GP_OUTER : GP_NB);
     for (int g = 0; g < count; ++g) gpk_set_identity(s, T + g * strideT, np, np);
     for (int c0 = 0; c0 < np; c0 += OB) {
@@ -474,6 +475,7 @@ gp_status gp_ctx_trim(gp_ctx *ctx) {
 
 gp_status gp_ctx_sync(gp_ctx *ctx) {
     if (!ctx) return GP_EINVAL;
+    GP_HIP(ctx, hipSetDevice(ctx->device));
     GP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return GP_OK;
 }
@@ -488,6 +490,7 @@ gp_status gp_ctx_profile(gp_ctx *ctx, int mask) {
 
 gp_status gp_ctx_profile_read(gp_ctx *ctx, int which, int64_t *launches, double *total_ms, double *work) {
     if (!ctx || which <= 0 || which >= GP_PROF_NCLASSES) return GP_EINVAL;
+    GP_HIP(ctx, hipSetDevice(ctx->device));
     GP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     gp_prof_slot &p = ctx->prof[which];
     double ms = 0.0;
@@ -530,18 +533,21 @@ gp_status gp_dev_alloc(gp_ctx *ctx, size_t bytes, void **dptr) {
 }
 gp_status gp_dev_free(gp_ctx *ctx, void *dptr) {
     if (!ctx) return GP_EINVAL;
+    GP_HIP(ctx, hipSetDevice(ctx->device));
     GP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (dptr) GP_HIP(ctx, hipFree(dptr));
     return GP_OK;
 }
 gp_status gp_dev_upload(gp_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes) {
     if (!ctx) return GP_EINVAL;
+    GP_HIP(ctx, hipSetDevice(ctx->device));
     GP_HIP(ctx, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
     GP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return GP_OK;
 }
 gp_status gp_dev_download(gp_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes) {
     if (!ctx) return GP_EINVAL;
+    GP_HIP(ctx, hipSetDevice(ctx->device));
     GP_HIP(ctx, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
     GP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return GP_OK;
@@ -660,17 +666,20 @@ gp_status gp_model_refit_dev(gp_model *m, const double *theta, double sigma_nois
     if (!m) return GP_EINVAL;
     gp_ctx *ctx = m->ctx;
     GP_REQUIRE(ctx, m->has_x && theta, "model has no training inputs (built from a Gram matrix)");
+    GP_HIP(ctx, hipSetDevice(ctx->device));
     m->theta.assign(theta, theta + m->d + 2);
     m->sigma_noise = sigma_noise;
     gp_prof_begin(ctx, GP_PROF_GRAM);
     gpk_gram_sym(ctx->stream, m->dX, m->n, m->d, m->n, theta, m->dL, m->ldl, 0, std::isnan(sigma_noise) ? 0.0 : sigma_noise);
     gp_prof_end(ctx, GP_PROF_GRAM, 8.0 * m->n * (m->n + 1.0) / 2.0 + 8.0 * m->n * m->d);
     model_factor(m);
+    GP_LAUNCH_CHECK(ctx);
     return GP_OK;
 }
 
 gp_status gp_model_status(gp_model *m, int *info) {
     if (!m) return GP_EINVAL;
+    GP_HIP(m->ctx, hipSetDevice(m->ctx->device));
     int h = 0;
     GP_TRY(read_info(m->ctx, &h));
     m->last_info = h;
@@ -738,6 +747,7 @@ gp_status gp_fit_from_gram(gp_ctx *ctx, const double *K, int n, int ldk, const d
 gp_status gp_model_get(gp_model *m, int what, double *out, int ld) {
     if (!m || !out) return GP_EINVAL;
     gp_ctx *ctx = m->ctx;
+    GP_HIP(ctx, hipSetDevice(ctx->device));
     switch (what) {
         case GP_GET_L:
             GP_REQUIRE(ctx, ld >= m->n, "ld < n");
@@ -789,7 +799,7 @@ static gp_status predict_core(gp_model *mdl, const double *dXs, int m, int ldxs,
     GP_HIP(ctx, hipMemsetAsync(sumsq, 0, sizeof(double) * mp, s));
     GP_HIP(ctx, hipMemsetAsync(dots, 0, sizeof(double) * mp, s));
     const double *Lw = nullptr;
-    static const bool use_lw = [] { const char *e = getenv("GPCORE_POSTERIOR_LW"); return !e || atoi(e) != 0; }();
+    const bool use_lw = [] { const char *e = getenv("GPCORE_POSTERIOR_LW"); return !e || atoi(e) != 0; }();
     if (use_lw && mp / GP_NB >= rows_left_min()) {   // large batch: fold the panel solves into the GEMMs (see build_lw)
         if (!mdl->dLw) {
             hipError_t e = hipMalloc(&mdl->dLw, sizeof(double) * (size_t)np * np);
@@ -811,6 +821,7 @@ static gp_status predict_core(gp_model *mdl, const double *dXs, int m, int ldxs,
     }
     if (vt_out) *vt_out = Vt;
     if (mp_out) *mp_out = mp;
+    GP_LAUNCH_CHECK(ctx);
     return GP_OK;
 }
 
@@ -819,6 +830,7 @@ gp_status gp_predict_dev(gp_model *mdl, const double *dXs, int m, int ldxs, doub
     gp_ctx *ctx = mdl->ctx;
     GP_REQUIRE(ctx, mdl->has_x, "model was built from a Gram matrix");
     GP_REQUIRE(ctx, dXs && dmean && m >= 1 && ldxs >= m, "bad arguments");
+    GP_HIP(ctx, hipSetDevice(ctx->device));
     // The (batch x n) workspace Vt is never materialised for all m at once (config C5: 10^6 x 32768 doubles = 262 GB):
     // test points go through in batches whose Vt stays under ~32 GiB; 65 536 rows per batch already fill the chip (one round
     // of 512 resident tiles), 131 072 (two rounds) measured +0.9 % at n = 8192, more rows nothing (GPCORE_PREDICT_BATCH).
@@ -868,6 +880,194 @@ gp_status gp_predict(gp_model *mdl, const double *Xs, int m, int ldxs, double *m
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// Posterior from a factor the CALLER holds: GpPredictor.computePosterior(trainingData, testData, l, alphaVec[, kernelFunc])
+// gp/regression/GpPredictor.scala:45-58 -- the entry GP-UCB (gp/optimization/GPOptimizer.scala:91) and the GP-UKF
+// (dynamicalsystems/filtering/GPUnscentedKalmanFilter.scala:78-87,141-142) call.  Shared core: Vt (mp x np, one row per test
+// point) arrives holding K*; mean = K* alpha is taken first (gemv, columns ascending like Breeze's dgemv), then
+// Vt <- Vt L^-T (= V^T) with the row sums of squares for the diagonal variance.
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct host_factor {          // (L, alpha) uploaded into padded device buffers
+    double *dL = nullptr, *dinv = nullptr, *dalpha = nullptr;
+    int n = 0, np = 0;
+};
+
+gp_status upload_factor(gp_ctx *ctx, const double *L, int n, int ldl, const double *alpha, host_factor *f) {
+    hipStream_t s = ctx->stream;
+    const int np = gp_pad(n);
+    f->n = n, f->np = np;
+    GP_TRY(ws_get(ctx, WS_B, sizeof(double) * (size_t)np * np, &f->dL));
+    GP_TRY(ws_get(ctx, WS_E, sizeof(double) * (size_t)np * 16, &f->dinv));
+    GP_TRY(ws_get(ctx, WS_F, sizeof(double) * (size_t)np, &f->dalpha));
+    GP_HIP(ctx, hipMemsetAsync(f->dL, 0, sizeof(double) * (size_t)np * np, s));
+    GP_HIP(ctx, hipMemsetAsync(f->dalpha, 0, sizeof(double) * (size_t)np, s));
+    GP_TRY(upload_2d(ctx, f->dL, np, L, ldl, n, n));
+    gpk_zero_upper(s, f->dL, n, np);          // callers pass breeze's cholesky output, but a full matrix must not leak in
+    gpk_pad_identity(s, f->dL, n, np, np);
+    gpk_tile_inverses(s, f->dL, np, np, f->dinv);
+    GP_TRY(upload_2d(ctx, f->dalpha, n, alpha, n, n, 1));
+    return GP_OK;
+}
+
+// Vt holds K* (m x n valid, pads zero) on entry and V^T on exit; dout = [mean (mp) | var or sumsq (mp)]
+gp_status posterior_rows(gp_ctx *ctx, double *Vt, int m, int mp, const host_factor &f, double *dmean, double *dsumsq) {
+    hipStream_t s = ctx->stream;
+    double *partial;
+    GP_TRY(ws_get(ctx, WS_PARTIAL, sizeof(double) * (size_t)16 * mp, &partial));
+    gpk_gemv_rows(s, Vt, m, f.n, mp, f.dalpha, dmean, partial, 16);
+    GP_HIP(ctx, hipMemsetAsync(dsumsq, 0, sizeof(double) * mp, s));
+    solve_rows_lower(ctx, Vt, mp, f.dL, f.np, f.np, f.dinv, dsumsq);
+    GP_LAUNCH_CHECK(ctx);
+    return GP_OK;
+}
+
+// cov (m x m, host) = dC - Vt Vt^T, dC (mp x mp, lower valid, pad identity) already holding the test Gram matrix
+gp_status cov_finish(gp_ctx *ctx, double *dC, int m, int mp, const double *Vt, int np, double *cov, int ldc) {
+    gp_prof_begin(ctx, GP_PROF_SYRK);
+    gpk_gemm_nt(ctx->stream, mp, mp, np, -1.0, Vt, mp, Vt, mp, 1.0, dC, mp, 1);
+    gp_prof_end(ctx, GP_PROF_SYRK, syrk_flops(mp, np));
+    GP_TRY(download_2d(ctx, cov, ldc, dC, mp, m, m));
+    for (int j = 0; j < m; ++j)
+        for (int i = 0; i < j; ++i) cov[i + (size_t)j * ldc] = cov[j + (size_t)i * ldc];
+    return GP_OK;
+}
+
+// V (n x m, host) = (Vt)^T
+gp_status v_download(gp_ctx *ctx, const double *Vt, int m, int mp, int n, int np, double *V, int ldv) {
+    double *dV;
+    GP_TRY(ws_get(ctx, WS_G, sizeof(double) * (size_t)np * mp, &dV));
+    gpk_transpose(ctx->stream, dV, np, Vt, mp, mp, np);
+    return download_2d(ctx, V, ldv, dV, np, n, m);
+}
+
+}  // namespace
+
+extern "C" gp_status gp_posterior_from_factor(gp_ctx *ctx, const double *X, int n, int d, int ldx, const double *theta, const double *L, int ldl,
+                                              const double *alpha, const double *Xs, int m, int ldxs, double *mean, double *var_diag,
+                                              double *cov, int ldc, double *V, int ldv) {
+    if (!ctx) return GP_EINVAL;
+    GP_REQUIRE(ctx, X && theta && L && alpha && Xs && mean, "null pointer");
+    GP_REQUIRE(ctx, n >= 1 && d >= 1 && d <= 64 && ldx >= n && ldl >= n && m >= 0 && ldxs >= m, "bad dimensions (n >= 1, 1 <= d <= 64)");
+    GP_REQUIRE(ctx, (!cov || ldc >= m) && (!V || ldv >= n), "bad leading dimension of an output");
+    if (m == 0) return GP_OK;
+    GP_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    host_factor f;
+    GP_TRY(upload_factor(ctx, L, n, ldl, alpha, &f));
+    const int np = f.np, mp = gp_pad(m);
+    double *dX, *dXs, *Vt, *dout;
+    GP_TRY(ws_get(ctx, WS_A, sizeof(double) * (size_t)m * d, &dXs));
+    GP_TRY(ws_get(ctx, WS_H, sizeof(double) * (size_t)n * d, &dX));
+    GP_TRY(ws_get(ctx, WS_VT, sizeof(double) * (size_t)mp * np, &Vt));
+    GP_TRY(ws_get(ctx, WS_C, sizeof(double) * (size_t)2 * mp, &dout));
+    GP_TRY(upload_2d(ctx, dXs, m, Xs, ldxs, m, d));
+    GP_TRY(upload_2d(ctx, dX, n, X, ldx, n, d));
+    GP_HIP(ctx, hipMemsetAsync(Vt, 0, sizeof(double) * (size_t)mp * np, s));
+    gp_prof_begin(ctx, GP_PROF_GRAM);
+    gpk_gram_cross(s, dXs, m, m, dX, n, n, d, theta, Vt, mp);
+    gp_prof_end(ctx, GP_PROF_GRAM, 8.0 * m * (double)n + 8.0 * (m + n) * d);
+    GP_TRY(posterior_rows(ctx, Vt, m, mp, f, dout, dout + mp));
+    GP_TRY(download_2d(ctx, mean, m, dout, m, m, 1));
+    if (var_diag) {
+        const double sf = theta[0], sn = theta[d + 1];
+        gpk_var_finish(s, dout + mp, dout + mp, m, sf * sf + sn * sn);
+        GP_TRY(download_2d(ctx, var_diag, m, dout + mp, m, m, 1));
+    }
+    if (cov) {   // buildKernelMatrix(kernelFunc, testData) - vMatrix.t * vMatrix   (:56)
+        double *dC;
+        GP_TRY(ws_get(ctx, WS_D, sizeof(double) * (size_t)mp * mp, &dC));
+        gpk_gram_sym(s, dXs, m, d, m, theta, dC, mp, 1, 0.0);
+        gpk_pad_identity(s, dC, m, mp, mp);
+        GP_TRY(cov_finish(ctx, dC, m, mp, Vt, np, cov, ldc));
+    }
+    if (V) GP_TRY(v_download(ctx, Vt, m, mp, n, np, V, ldv));
+    return GP_OK;
+}
+
+// Same for ANY KernelFunc: the caller evaluated K* = buildKernelMatrix(kernelFunc, testData, trainingData) (m x n) and, for the
+// covariance, K** = buildKernelMatrix(kernelFunc, testData) (m x m) -- or only its diagonal -- on the host.
+extern "C" gp_status gp_posterior_from_gram(gp_ctx *ctx, const double *Ks, int m, int n, int ldks, const double *Kss, int ldkss,
+                                            const double *kss_diag, const double *L, int ldl, const double *alpha, double *mean,
+                                            double *var_diag, double *cov, int ldc, double *V, int ldv) {
+    if (!ctx) return GP_EINVAL;
+    GP_REQUIRE(ctx, Ks && L && alpha && mean, "null pointer");
+    GP_REQUIRE(ctx, n >= 1 && m >= 0 && ldks >= m && ldl >= n, "bad dimensions");
+    GP_REQUIRE(ctx, (!cov || (Kss && ldkss >= m && ldc >= m)) && (!var_diag || Kss || kss_diag) && (!V || ldv >= n) && (!Kss || ldkss >= m),
+               "cov needs Kss, var_diag needs Kss or kss_diag");
+    if (m == 0) return GP_OK;
+    GP_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    host_factor f;
+    GP_TRY(upload_factor(ctx, L, n, ldl, alpha, &f));
+    const int np = f.np, mp = gp_pad(m);
+    double *Vt, *dout;
+    GP_TRY(ws_get(ctx, WS_VT, sizeof(double) * (size_t)mp * np, &Vt));
+    GP_TRY(ws_get(ctx, WS_C, sizeof(double) * (size_t)2 * mp, &dout));
+    GP_HIP(ctx, hipMemsetAsync(Vt, 0, sizeof(double) * (size_t)mp * np, s));
+    GP_TRY(upload_2d(ctx, Vt, mp, Ks, ldks, m, n));
+    GP_TRY(posterior_rows(ctx, Vt, m, mp, f, dout, dout + mp));
+    GP_TRY(download_2d(ctx, mean, m, dout, m, m, 1));
+    if (var_diag) {
+        GP_TRY(download_2d(ctx, var_diag, m, dout + mp, m, m, 1));
+        for (int i = 0; i < m; ++i) var_diag[i] = (Kss ? Kss[i + (size_t)i * ldkss] : kss_diag[i]) - var_diag[i];
+    }
+    if (cov) {
+        double *dC;
+        GP_TRY(ws_get(ctx, WS_D, sizeof(double) * (size_t)mp * mp, &dC));
+        GP_HIP(ctx, hipMemsetAsync(dC, 0, sizeof(double) * (size_t)mp * mp, s));
+        GP_TRY(upload_2d(ctx, dC, mp, Kss, ldkss, m, m));
+        GP_TRY(cov_finish(ctx, dC, m, mp, Vt, np, cov, ldc));
+    }
+    if (V) GP_TRY(v_download(ctx, Vt, m, mp, n, np, V, ldv));
+    return GP_OK;
+}
+
+// predict() for a model fitted with gp_fit_from_gram (GpPredictor.predict with a user KernelFunc such as Co2Kernel,
+// gp/regression/Co2Prediction.scala:29-137): the factor and alpha are already resident, only K* / K** come from the host.
+extern "C" gp_status gp_predict_from_gram(gp_model *mdl, const double *Ks, int m, int ldks, const double *Kss, int ldkss,
+                                          const double *kss_diag, double *mean, double *var_diag, double *cov, int ldc) {
+    if (!mdl) return GP_EINVAL;
+    gp_ctx *ctx = mdl->ctx;
+    GP_REQUIRE(ctx, Ks && mean && m >= 0 && ldks >= m, "bad arguments");
+    GP_REQUIRE(ctx, (!cov || (Kss && ldkss >= m && ldc >= m)) && (!var_diag || Kss || kss_diag) && (!Kss || ldkss >= m),
+               "cov needs Kss, var_diag needs Kss or kss_diag");
+    if (m == 0) return GP_OK;
+    GP_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const int n = mdl->n, np = mdl->np, mp = gp_pad(m);
+    ensure_alpha(mdl);
+    host_factor f;
+    f.dL = mdl->dL, f.dinv = mdl->ddinv, f.dalpha = mdl->dalpha, f.n = n, f.np = np;
+    double *Vt, *dout;
+    GP_TRY(ws_get(ctx, WS_VT, sizeof(double) * (size_t)mp * np, &Vt));
+    GP_TRY(ws_get(ctx, WS_C, sizeof(double) * (size_t)2 * mp, &dout));
+    GP_HIP(ctx, hipMemsetAsync(Vt, 0, sizeof(double) * (size_t)mp * np, s));
+    GP_TRY(upload_2d(ctx, Vt, mp, Ks, ldks, m, n));
+    {   // posterior_rows with the model's leading dimension (ldl = np + 128)
+        double *partial;
+        GP_TRY(ws_get(ctx, WS_PARTIAL, sizeof(double) * (size_t)16 * mp, &partial));
+        gpk_gemv_rows(s, Vt, m, n, mp, f.dalpha, dout, partial, 16);
+        GP_HIP(ctx, hipMemsetAsync(dout + mp, 0, sizeof(double) * mp, s));
+        solve_rows_lower(ctx, Vt, mp, mdl->dL, np, mdl->ldl, mdl->ddinv, dout + mp);
+        GP_LAUNCH_CHECK(ctx);
+    }
+    GP_TRY(download_2d(ctx, mean, m, dout, m, m, 1));
+    if (var_diag) {
+        GP_TRY(download_2d(ctx, var_diag, m, dout + mp, m, m, 1));
+        for (int i = 0; i < m; ++i) var_diag[i] = (Kss ? Kss[i + (size_t)i * ldkss] : kss_diag[i]) - var_diag[i];
+    }
+    if (cov) {
+        double *dC;
+        GP_TRY(ws_get(ctx, WS_D, sizeof(double) * (size_t)mp * mp, &dC));
+        GP_HIP(ctx, hipMemsetAsync(dC, 0, sizeof(double) * (size_t)mp * mp, s));
+        GP_TRY(upload_2d(ctx, dC, mp, Kss, ldkss, m, m));
+        GP_TRY(cov_finish(ctx, dC, m, mp, Vt, np, cov, ldc));
+    }
+    return GP_OK;
+}
 
 // ------------------------------------------------------------------------------------------------
 // generic triangular solves with many right-hand sides, through the row-panel machinery:
@@ -1000,6 +1200,7 @@ gp_status lml_worker_eval(lml_worker &w, const double *thetas, int g, int nparam
             gpk_lml_grad_traces(s, w.dX, n, d, n, thetas + (size_t)j * P, w.alpha(j), w.Kinv + j * w.sT, np, w.partials + j * w.sPart, w.res(j) + 1);
         }
     }
+    GP_LAUNCH_CHECK(ctx);
     GP_HIP(ctx, hipMemcpy2DAsync(w.hres.data(), 72 * sizeof(double), w.res(0), w.sSmall * sizeof(double), (P + 1) * sizeof(double), g,
                                  hipMemcpyDeviceToHost, s));
     GP_HIP(ctx, hipMemcpyAsync(w.hinfo.data(), w.info, sizeof(int) * g, hipMemcpyDeviceToHost, s));
@@ -1063,6 +1264,9 @@ extern "C" gp_status gp_lml_grad_rbf_batched(gp_ctx *ctx, const double *X, int n
             w.st = lml_worker_eval(w, thetas + (size_t)b * P, g, nparams, sigma_noise, lml + b, grad ? grad + (size_t)b * nparams : nullptr,
                                    info ? info + b : nullptr);
         }
+        // a worker that found no group left still has its uploads of the caller's X, y in flight: the host buffers may
+        // be released as soon as this function returns
+        (void)hipStreamSynchronize(w.ctx->stream);
     };
     std::vector<std::thread> threads;
     for (int k = 1; k < nw; ++k) threads.emplace_back(run, k);

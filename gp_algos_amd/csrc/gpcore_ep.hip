@@ -460,6 +460,7 @@ gp_status gp_ep_sweep(gp_ep *ep, int nsweeps, double *tau, double *nu, int *info
             }
         }
         GP_TRY(ep_refactor(ep));
+        GP_LAUNCH_CHECK(ctx);
         ep->sweeps += 1;
     }
     int h = 0;
@@ -493,6 +494,7 @@ gp_status gp_ep_lml(gp_ep *ep, int strict, double *lml) {
     if (!ep || !lml) return GP_EINVAL;
     gp_ctx *ctx = ep->ctx;
     GP_REQUIRE(ctx, ep->sweeps > 0, "no sweep has run yet");
+    GP_HIP(ctx, hipSetDevice(ctx->device));
     hipLaunchKernelGGL(ep_lml_kernel, dim3(1), dim3(1024), 0, ctx->stream, ep->n, ep->np, ep->L, ep->tau(), ep->nu(), ep->mu(),
                        ep->cav_tau(), ep->cav_nu(), ep->y, strict, ctx->d_scalars);
     return gpi_download_2d(ctx, lml, 1, ctx->d_scalars, 1, 1, 1);
@@ -544,6 +546,7 @@ gp_status gp_ep_get(gp_ep *ep, int what, double *out, int ld) {
     if (!ep || !out) return GP_EINVAL;
     gp_ctx *ctx = ep->ctx;
     const int n = ep->n, np = ep->np;
+    GP_HIP(ctx, hipSetDevice(ctx->device));
     switch (what) {
         case GP_EP_GET_L: GP_REQUIRE(ctx, ld >= n, "ld < n"); return gpi_download_2d(ctx, out, ld, ep->L, np, n, n);
         case GP_EP_GET_SIGMA: GP_REQUIRE(ctx, ld >= n, "ld < n"); return gpi_download_2d(ctx, out, ld, ep->Sig, np, n, n);

@@ -16,6 +16,13 @@ constexpr int GP_NB = 128;   // Cholesky panel width == GEMM tile edge
 constexpr int GP_BK = 16;    // GEMM k-step
 constexpr int GP_OUTER = 512; // outer panel width of the two-level Cholesky (trailing update runs with K = 512)
 static inline int gp_pad(int n) { return (n + GP_NB - 1) / GP_NB * GP_NB; }
+// tuning knob given as a column count: a positive multiple of GP_NB, else 0 (= use the default).  Read on every call, so a
+// test can switch the blocked algorithms between their forms inside one process.
+static inline int gp_env_blocks(const char *name) {
+    const char *e = getenv(name);
+    const int v = e ? atoi(e) : 0;
+    return (v >= GP_NB && v % GP_NB == 0) ? v : 0;
+}
 
 struct gp_prof_slot {
     int64_t launches = 0;
@@ -63,6 +70,8 @@ struct gp_model {
 #define GP_SET_ERR(ctx, ...) do { if (ctx) snprintf((ctx)->err, sizeof((ctx)->err), __VA_ARGS__); } while (0)
 #define GP_HIP(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
     GP_SET_ERR(ctx, "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); return GP_EHIP; } } while (0)
+// after a sequence of kernel launches: a launch that failed (bad configuration, wrong device current) must not go unnoticed
+#define GP_LAUNCH_CHECK(ctx) GP_HIP(ctx, hipGetLastError())
 #define GP_REQUIRE(ctx, cond, msg) do { if (!(cond)) { GP_SET_ERR(ctx, "invalid argument: %s", msg); return GP_EINVAL; } } while (0)
 #define GP_TRY(call) do { gp_status s_ = (call); if (s_ != GP_OK) return s_; } while (0)
 
@@ -133,7 +142,7 @@ void gpk_tile_inverses(hipStream_t s, const double *L, int np, int ldl, double *
 void gpk_copy_strided(hipStream_t s, double *dst, size_t dst_stride, const double *src, size_t src_stride, int count);
 
 // ---- host-side helpers shared between translation units (defined in gpcore_api.hip) ----
-enum { WS_VT = 0, WS_PARTIAL, WS_SUMSQ, WS_A, WS_B, WS_C, WS_D, WS_E, WS_COUNT };
+enum { WS_VT = 0, WS_PARTIAL, WS_SUMSQ, WS_A, WS_B, WS_C, WS_D, WS_E, WS_F, WS_G, WS_H, WS_COUNT };
 gp_status gpi_ws_get(gp_ctx *ctx, int slot, size_t bytes, double **out);
 gp_status gpi_upload_2d(gp_ctx *ctx, double *dst, int ldd, const double *src, int lds, int rows, int cols);
 gp_status gpi_download_2d(gp_ctx *ctx, double *dst, int ldd, const double *src, int lds, int rows, int cols);

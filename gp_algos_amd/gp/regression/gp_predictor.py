@@ -79,7 +79,7 @@ class GpPredictor:
             if isinstance(kf, GaussianRbfKernel):
                 mean, _, cov = mdl.predict(Xs, full_cov=True)
             else:
-                mean, cov = self._posterior_from_host_gram(kf, input.trainingData, Xs, mdl.L(), mdl.alpha())
+                mean, cov = self._posterior_from_host_gram(kf, input.trainingData, Xs, mdl)
             if input.sigmaNoise is not None:
                 # fVariance + noiseDiagMtx.get (:37-39): an n x n matrix added to an m x m one -- only defined for m == n
                 if cov.shape[0] != mdl.n:
@@ -90,17 +90,26 @@ class GpPredictor:
             mdl.close()
 
     def computePosterior(self, trainingData, testData, l, alphaVec, kernelFunc=None):   # :45-58
+        """(GaussianDistribution(fMean, fVariance), vMatrix) from a factor the caller holds.  GaussianRbfKernel: everything
+        on the device (gp_posterior_from_factor); any other KernelFunc: K* and K** by the reference's per-pair loops on the host,
+        the O(n^2 m) solve and the m^2 n product on the device (gp_posterior_from_gram)."""
         kf = self.kernelFunc if kernelFunc is None else kernelFunc
+        X = np.asfortranarray(np.asarray(trainingData, dtype=np.float64))
         Xs = np.asfortranarray(np.asarray(testData, dtype=np.float64))
-        Ks = matrix_utils.buildKernelMatrix(kf, Xs, trainingData)
-        fMean = Ks @ np.asarray(alphaVec, dtype=np.float64)
-        vMatrix = matrix_utils.forwardSolve(l, np.asfortranarray(Ks.T))
-        fVariance = matrix_utils.buildKernelMatrix(kf, Xs) - vMatrix.T @ vMatrix
-        return GaussianDistribution(mean=fMean, sigma=fVariance), vMatrix
+        ctx = default_context()
+        if isinstance(kf, GaussianRbfKernel):
+            mean, _, cov, V = ctx.posterior_from_factor(X, kf.rbfParams.toDenseVector(), l, alphaVec, Xs, full_cov=True, want_v=True)
+        else:
+            Ks = matrix_utils.buildKernelMatrix(kf, Xs, X)
+            Kss = matrix_utils.buildKernelMatrix(kf, Xs)
+            mean, _, cov, V = ctx.posterior_from_gram(Ks, l, alphaVec, Kss=Kss, want_v=True)
+        return GaussianDistribution(mean=mean, sigma=cov), V
 
-    def _posterior_from_host_gram(self, kf, trainingData, Xs, L, alpha):
-        dist, _ = self.computePosterior(trainingData, Xs, L, alpha, kf)
-        return dist.mean, dist.sigma
+    def _posterior_from_host_gram(self, kf, trainingData, Xs, mdl):
+        Ks = matrix_utils.buildKernelMatrix(kf, Xs, trainingData)
+        Kss = matrix_utils.buildKernelMatrix(kf, Xs)
+        mean, _, cov = mdl.predict_from_gram(Ks, Kss=Kss)
+        return mean, cov
 
     def logLikelihoodWithDerivatives(self, input, hyperParams, optimizedParamsNum):   # :60-80
         kf = self.kernelFunc.changeHyperParams(hyperParams.toDenseVector())

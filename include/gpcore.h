@@ -113,7 +113,7 @@ gp_status gp_inv_lower(gp_ctx *ctx, const double *L, int n, int ldl, double *Lin
 gp_status gp_fit_rbf(gp_ctx *ctx, const double *X, int n, int d, int ldx, const double *y, const double *theta, double sigma_noise, gp_model **out, int *info);
 gp_status gp_fit_rbf_dev(gp_ctx *ctx, const double *dX, int n, int d, int ldx, const double *dy, const double *theta, double sigma_noise, gp_model **out, int *info);
 /* Same with a host-built Gram matrix (any KernelFunc, e.g. Co2Kernel gp/regression/Co2Prediction.scala:29).
- * Such a model supports gp_model_get only (the caller forms K* itself and solves with gp_trsm_lower). */
+ * Such a model supports gp_model_get and gp_predict_from_gram (the caller evaluates K* and K** with its own kernel). */
 gp_status gp_fit_from_gram(gp_ctx *ctx, const double *K, int n, int ldk, const double *y, gp_model **out, int *info);
 /* Re-fit an existing model in place (same n, d): no allocation, fully asynchronous. */
 gp_status gp_model_refit_dev(gp_model *model, const double *theta, double sigma_noise);
@@ -129,6 +129,21 @@ void gp_model_destroy(gp_model *model);
 gp_status gp_predict(gp_model *model, const double *Xs, int m, int ldxs, double *mean, double *var_diag, double *cov, int ldc);
 /* device-resident variant: dXs (m x d), dmean[m], dvar[m] in HBM; asynchronous. */
 gp_status gp_predict_dev(gp_model *model, const double *dXs, int m, int ldxs, double *dmean, double *dvar);
+/* GpPredictor.computePosterior(trainingData, testData, l, alphaVec), gp/regression/GpPredictor.scala:45-58, for a factor the
+ * CALLER holds (the entry GP-UCB, gp/optimization/GPOptimizer.scala:91, and the GP-UKF,
+ * dynamicalsystems/filtering/GPUnscentedKalmanFilter.scala:78-87,141-142, use): mean = K* alpha,
+ * V = forwardSolve(L, K*^T), Sigma* = buildKernelMatrix(X*) - V^T V with the ARD-RBF kernel at theta.  L is n x n (lower
+ * triangle read), alpha[n].  mean[m] required; var_diag[m], cov (m x m, ldc) and V (n x m, ldv -- the second member of the
+ * Scala return tuple) are optional. */
+gp_status gp_posterior_from_factor(gp_ctx *ctx, const double *X, int n, int d, int ldx, const double *theta, const double *L, int ldl, const double *alpha, const double *Xs, int m, int ldxs, double *mean, double *var_diag, double *cov, int ldc, double *V, int ldv);
+/* The same overload with an explicit kernelFunc (GpPredictor.scala:50-58) for ANY KernelFunc (Co2Kernel,
+ * gp/regression/Co2Prediction.scala:29): the caller evaluates Ks = buildKernelMatrix(kernelFunc, testData, trainingData)
+ * (m x n) and, for the covariance, Kss = buildKernelMatrix(kernelFunc, testData) (m x m) on the host; kss_diag[m] suffices
+ * for var_diag alone.  cov requires Kss; var_diag requires Kss or kss_diag. */
+gp_status gp_posterior_from_gram(gp_ctx *ctx, const double *Ks, int m, int n, int ldks, const double *Kss, int ldkss, const double *kss_diag, const double *L, int ldl, const double *alpha, double *mean, double *var_diag, double *cov, int ldc, double *V, int ldv);
+/* GpPredictor.predict (:24-43) for a model fitted with gp_fit_from_gram: factor and alpha stay resident, only the host-built
+ * Ks (m x n) and Kss / kss_diag cross the boundary. */
+gp_status gp_predict_from_gram(gp_model *model, const double *Ks, int m, int ldks, const double *Kss, int ldkss, const double *kss_diag, double *mean, double *var_diag, double *cov, int ldc);
 
 /* ---- log marginal likelihood + gradient ------------------------------------------------------ */
 /* GpPredictor.logLikelihoodWithDerivatives, gp/regression/GpPredictor.scala:60-80, evaluated at B

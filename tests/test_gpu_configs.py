@@ -1,0 +1,206 @@
+"""BASELINE.json configurations C3, C4, C5 at their FULL sizes through the C-ABI, and the lockstep batched LML + gradient
+path past one outer panel (np > 512 with several settings per launch) against the oracle.
+
+The oracle (scalar loops in the reference's order) finishes n <= ~1100 in seconds, so the lockstep path is compared with it
+setting by setting there.  At n = 4096 / 32768 parity rests on size-independent identities evaluated by an independent
+numpy/LAPACK path on the host (K rebuilt from X in numpy, never taken from the device):
+  C3  LML = -1/2 y.alpha - sum log diag(chol K) - n/2 log 2 pi and g_p = 1/2 tr((alpha alpha^T - K^-1) dK/dtheta_p)
+      (GpPredictor.scala:60-80,144-149) from scipy's Cholesky for a sample of the 64 settings, all P components
+  C4  after 50 sweeps: Sigma (I + diag(tau) K) = K, mu = Sigma nu, Sigma symmetric (EpParameterEstimator.scala:56-61),
+      and the sweep is at its fixed point (one more sweep moves tau, nu by < 1e-6 relative)
+  C5  (K alpha)_i = y_i and mean_j = k*_j . alpha on sampled rows, 0 < var <= sf^2 + sn^2, the large-batch posterior path
+      against the small-batch one and two points against the oracle's scalar substitution."""
+import numpy as np
+import pytest
+
+from gp_algos_amd import synth
+from oracle import gp_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+TOL_LML = 1e-11
+TOL_GRAD = 1e-8
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from gp_algos_amd.core import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+# ---- lockstep batch past one outer panel ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,d,B,workers,tinv_outer", [
+    (700, 3, 9, "1", None),      # one group of 9: batched K = 512 trailing update, two-level T = L^-T (count >= 4 -> 512)
+    (700, 3, 9, "1", "128"),     # same group, plain right-looking T = L^-T
+    (1100, 2, 6, "1", None),     # np = 1152: two full outer panels + a partial one, one group of 6
+    (1100, 2, 6, "2", "512"),    # two workers x groups of 3 (count < 4), two-level form forced
+    (1100, 2, 5, "2", None),     # ragged: groups of 3 and 2, default forms
+])
+def test_lockstep_batch_across_outer_panels_vs_oracle(ctx, monkeypatch, n, d, B, workers, tinv_outer):
+    """chol_blocked's batched K = 512 trailing update (count > 1), inverse_transpose_lower's `right > 0` branch and the batched
+    T T^T with more than 8 tile rows: every setting of the group against orc.lml_grad (GpPredictor.scala:60-80)."""
+    monkeypatch.setenv("GPCORE_LML_WORKERS", workers)
+    if tinv_outer is None:
+        monkeypatch.delenv("GPCORE_TINV_OUTER", raising=False)
+    else:
+        monkeypatch.setenv("GPCORE_TINV_OUTER", tinv_outer)
+    p = synth.regression(n, d, 0, 300 + n, 301 + n, 0, synth.ard_theta(d, 1.2, 1.0, 0.15))
+    rng = np.random.default_rng(n + B)
+    thetas = p["theta"][None, :] * rng.uniform(0.6, 1.7, size=(B, d + 2))
+    lml, grad, info = ctx.lml_grad_batched(p["X"], p["y"], thetas)
+    assert np.all(info == 0)
+    for b in range(B):
+        ol, og = orc.lml_grad(p["X"], p["y"], thetas[b])
+        assert abs(lml[b] - ol) <= TOL_LML * abs(ol), b
+        assert np.max(np.abs(grad[b] - og)) <= TOL_GRAD * np.max(np.abs(og)), b
+    # the same setting alone (count = 1: single-problem forms of every step) agrees to rounding
+    one, gone, _ = ctx.lml_grad_batched(p["X"], p["y"], thetas[B - 1:B])
+    assert abs(one[0] - lml[B - 1]) <= 1e-12 * abs(one[0])
+    assert np.max(np.abs(gone[0] - grad[B - 1])) <= 1e-10 * np.max(np.abs(gone[0]))
+
+
+def test_lockstep_batch_with_a_non_pd_member_past_one_outer_panel(ctx, monkeypatch):
+    """A non-PD setting inside a lockstep group at np = 768: its failing pivot is reported, its group mates still match."""
+    monkeypatch.setenv("GPCORE_LML_WORKERS", "1")
+    p = synth.regression(640, 2, 0, 77, 78, 0, synth.ard_theta(2, 1.1, 1.0, 0.2))
+    X = np.asfortranarray(np.vstack([p["X"], p["X"][:30]]))      # 30 duplicated rows: singular without noise
+    y = np.concatenate([p["y"], p["y"][:30]])
+    thetas = p["theta"][None, :] * np.random.default_rng(9).uniform(0.7, 1.5, size=(5, 4))
+    thetas[2, -1] = 0.0
+    lml, grad, info = ctx.lml_grad_batched(X, y, thetas)
+    assert 0 < info[2] <= 670 and np.isnan(lml[2]) and np.all(np.isnan(grad[2]))   # 1-based failing pivot (where exactly is rounding)
+    for b in (0, 1, 3, 4):
+        ol, og = orc.lml_grad(X, y, thetas[b])
+        assert info[b] == 0 and abs(lml[b] - ol) <= TOL_LML * abs(ol)
+        assert np.max(np.abs(grad[b] - og)) <= TOL_GRAD * np.max(np.abs(og))
+
+
+# ---- C3 at full size -------------------------------------------------------------------------------------------------------
+def _host_lml_grad(X, y, theta):
+    """Closed forms of GpPredictor.scala:60-80,144-149 on LAPACK (independent of the device and of the oracle's loops)."""
+    import scipy.linalg as sla
+    n, d = X.shape
+    sf, ell, sn = theta[0], theta[1:-1], theta[-1]
+    Z = X / ell
+    sq = (Z * Z).sum(axis=1)
+    E = np.exp(-0.5 * np.maximum(sq[:, None] + sq[None, :] - 2.0 * Z @ Z.T, 0.0))
+    np.fill_diagonal(E, 1.0)
+    K = sf * sf * E
+    K[np.diag_indices(n)] += sn * sn
+    c = sla.cho_factor(K, lower=True, check_finite=False)
+    alpha = sla.cho_solve(c, y, check_finite=False)
+    lml = -0.5 * y @ alpha - np.log(np.diag(c[0])).sum() - 0.5 * n * np.log(2 * np.pi)
+    W = np.outer(alpha, alpha) - sla.cho_solve(c, np.eye(n), check_finite=False)
+    WE = W * E
+    g = np.zeros(d + 2)
+    g[0] = sf * WE.sum()
+    for k in range(d):
+        D2 = (X[:, k][:, None] - X[:, k][None, :]) ** 2
+        g[1 + k] = 0.5 * sf * sf / ell[k] ** 3 * (WE * D2).sum()
+    g[d + 1] = sn * np.trace(W)
+    return lml, g
+
+
+def test_c3_full_size_all_64_settings(ctx):
+    """Config C3 as benchmarked: n = 4096, d = 8, all 64 settings in lockstep groups of 32 on two workers."""
+    p = synth.config_c3(4096, 8)
+    B = p["thetas"].shape[0]
+    assert B == 64
+    lml, grad, info = ctx.lml_grad_batched(p["X"], p["y"], p["thetas"])
+    assert np.all(info == 0) and np.all(np.isfinite(lml)) and np.all(np.isfinite(grad))
+    for b in (0, 13, 21, 38, 47, 63):                 # corners and interior of the 4 x 4 x 4 grid
+        hl, hg = _host_lml_grad(p["X"], p["y"], p["thetas"][b])
+        assert abs(lml[b] - hl) <= 1e-10 * abs(hl), b
+        assert np.max(np.abs(grad[b] - hg)) <= 1e-7 * np.max(np.abs(hg)), b
+    # group members do not influence each other: three settings alone (count = 1) agree to rounding
+    for b in (5, 33, 62):
+        one, gone, _ = ctx.lml_grad_batched(p["X"], p["y"], p["thetas"][b:b + 1])
+        assert abs(one[0] - lml[b]) <= 1e-12 * abs(one[0])
+        assert np.max(np.abs(gone[0] - grad[b])) <= 1e-9 * np.max(np.abs(gone[0]))
+    # central differences on three settings (two LML-only evaluations each, batched)
+    for b, k in ((21, 0), (21, 4), (40, 9)):
+        th = p["thetas"][b]
+        h = 1e-5 * abs(th[k])
+        tp, tm = th.copy(), th.copy()
+        tp[k] += h
+        tm[k] -= h
+        (lp, lm_), _, _ = ctx.lml_grad_batched(p["X"], p["y"], np.stack([tp, tm]), nparams=0)
+        assert abs((lp - lm_) / (2 * h) - grad[b, k]) <= 2e-5 * max(1.0, abs(grad[b, k]))
+
+
+# ---- C4 at full size -------------------------------------------------------------------------------------------------------
+def test_c4_full_size_50_sweeps(ctx):
+    """Config C4 as benchmarked: n = 4096, 50 EP sweeps (EpParameterEstimator.scala:29-69)."""
+    from gp_algos_amd import _lib as L
+    from gp_algos_amd.core import EpClassifierState
+    n = 4096
+    p = synth.config_c4(n, 8)
+    K = ctx.gram_rbf(p["X"], p["theta"])
+    K[np.diag_indices_from(K)] += 1e-6     # the C4 kernel has sn = 0: keep K numerically PD for the host-side identity
+    ep = EpClassifierState(ctx, K, p["y"])
+    tau, nu = ep.sweep(50)
+    assert np.all(np.isfinite(tau)) and np.all(np.isfinite(nu)) and np.all(tau > 0)
+    Sig, mu = ep.get(L.GP_EP_GET_SIGMA), ep.get(L.GP_EP_GET_MU)
+    V = np.random.default_rng(1).standard_normal((n, 3))
+    KV = K @ V
+    lhs = Sig @ (V + tau[:, None] * KV)
+    assert np.linalg.norm(lhs - KV) / np.linalg.norm(KV) <= 1e-9
+    assert np.max(np.abs(Sig @ nu - mu)) <= 1e-9 * np.max(np.abs(mu))
+    assert np.array_equal(Sig, Sig.T)
+    Lf = ep.get(L.GP_EP_GET_L)              # L L^T = I + S^1/2 K S^1/2  (:56-58)
+    st = np.sqrt(tau)
+    BV = V + st[:, None] * (K @ (st[:, None] * V))
+    assert np.linalg.norm(Lf @ (Lf.T @ V) - BV) / np.linalg.norm(BV) <= 1e-12
+    l_strict, l_corr = ep.lml(True), ep.lml(False)
+    assert np.isfinite(l_strict) and np.isfinite(l_corr) and l_strict != l_corr
+    # labels agree with the latent mean on the training set far better than chance
+    assert np.mean(np.sign(mu) == p["y"]) > 0.85
+    # 50 sweeps is a fixed point of the sweep map
+    tau2, nu2 = ep.sweep(1)
+    assert np.max(np.abs(tau2 - tau)) <= 1e-6 * np.max(np.abs(tau))
+    assert np.max(np.abs(nu2 - nu)) <= 1e-6 * np.max(np.abs(nu))
+    ep.close()
+
+
+# ---- C5 at full size -------------------------------------------------------------------------------------------------------
+def test_c5_full_size_fit_and_large_batch_variances(ctx):
+    """Config C5 per GPU: n = 32768, d = 8 fit (8.6 GB factor, outer panel 1024) and one 131 072-point posterior batch."""
+    from gp_algos_amd.core import RegressionModel
+    n, d, m = 32768, 8, 131072
+    p = synth.config_c5(n, d, m)
+    sf2, sn2 = p["theta"][0] ** 2, p["theta"][-1] ** 2
+    mdl = RegressionModel(ctx, p["X"], p["y"], p["theta"])
+    alpha = mdl.alpha()
+    assert np.all(np.isfinite(alpha))
+    Z = p["X"] / p["theta"][1:-1]
+
+    def krow(z):
+        return sf2 * np.exp(-0.5 * ((Z - z) ** 2).sum(axis=1))
+
+    rng = np.random.default_rng(0)
+    idx = rng.choice(n, 64, replace=False)
+    errK = max(abs(krow(Z[i]) @ alpha + sn2 * alpha[i] - p["y"][i]) for i in idx)
+    assert errK <= 1e-8
+    mean, var, _ = mdl.predict(p["Xs"])
+    assert np.all(np.isfinite(mean)) and np.all(var > 0.0) and np.all(var <= sf2 + sn2 + 1e-9)
+    Zs = p["Xs"] / p["theta"][1:-1]
+    jdx = np.sort(rng.choice(m, 64, replace=False))
+    errM = max(abs(krow(Zs[j]) @ alpha - mean[j]) for j in jdx)
+    assert errM <= 1e-9 * max(1.0, np.max(np.abs(mean)))
+    # the same points through the small-batch (right-looking) path
+    m2, v2, _ = mdl.predict(np.asfortranarray(p["Xs"][jdx]))
+    assert np.max(np.abs(mean[jdx] - m2)) <= 1e-10 * max(1.0, np.max(np.abs(m2)))
+    assert np.max(np.abs(var[jdx] - v2)) <= 1e-10 * sf2
+    # LML from its definition with the device's own L diagonal and alpha
+    Lh = mdl.L()
+    lml = -0.5 * p["y"] @ alpha - np.log(np.diag(Lh)).sum() - 0.5 * n * np.log(2 * np.pi)
+    assert abs(mdl.lml() - lml) <= 1e-11 * abs(lml)
+    # two points against the oracle's scalar forward substitution (n^2 flops each)
+    om, ov, _, _ = orc.predict(p["X"], p["theta"], Lh, alpha, np.asfortranarray(p["Xs"][jdx[:2]]))
+    assert np.max(np.abs(mean[jdx[:2]] - om)) <= 1e-9 * max(1.0, np.max(np.abs(om)))
+    assert np.max(np.abs(var[jdx[:2]] - ov)) <= 1e-9 * sf2
+    del Lh
+    mdl.close()
+    ctx.trim()
