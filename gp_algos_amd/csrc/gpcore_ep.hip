@@ -26,13 +26,19 @@ struct gp_ep {
     int n = 0, np = 0;
     double *K = nullptr;      // np x np, full symmetric, pad = identity
     double *Sig = nullptr;    // np x np, full symmetric
-    double *L = nullptr;      // np x np lower
+    double *L = nullptr;      // (2 np) x np, ld = ldl = 2 np: rows [0, np) the lower factor of B = I + S^1/2 K S^1/2, rows [np, 2 np) ride through
+                              //   the factorisation and come out as Vt = (K S^1/2) L^-T  (V = L \ (S^1/2 K), :59)
+    int ldl = 0;
     double *dinv = nullptr;   // np x 16
     double *S = nullptr;      // np x 128 panel of delayed columns
     double *Sc = nullptr;     // np x 128 panel scaled by c
-    double *blk = nullptr;    // 128 x 128 unit-lower block factor + its 8 tile inverses
+    double *blk = nullptr;    // 2 x (128 x 128 unit-lower block factor + its 8 tile inverses), by block parity
     double *vec = nullptr;    // 10 x np: tau, nu, tau_old, nu_old, mu, cav_tau, cav_nu, st, tmp1, tmp2
-    double *cvec = nullptr;   // 128 c + 128 (-coef)
+    double *cvec = nullptr;   // 2 x (128 c + 128 coef), by block parity
+    std::vector<hipEvent_t> ev;   // 3 per block: block factor ready | next block's rows solved | side-stream update done
+    hipEvent_t ev_chol = nullptr, ev_parta = nullptr, ev_partb = nullptr;   // end-of-sweep refactorisation: see ep_refactor
+    bool side_pending = false;    // the side stream still owes the second part of Sigma / mu
+    bool sig_mirrored = false;    // the strict upper triangle of Sig mirrors the lower one (only gp_ep_get needs it)
     int *y = nullptr;
     int sweeps = 0;
     double *tau() { return vec; }
@@ -61,6 +67,11 @@ __device__ __forceinline__ double rcp_nr(double x) {
     e = fma(-x, r, 1.0);
     return fma(r, e, r);
 }
+__device__ __forceinline__ double rl64(double v, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double dnorm_d(double x) { return exp(-(x * x) / 2.0 - log(sqrt(2.0 * M_PI))); }   // StatsUtils.scala:15
 __device__ __forceinline__ double pnorm_d(double x) { return 0.5 * (1.0 + erf(x / sqrt(2.0))); }              // StatsUtils.scala:17
 
@@ -76,7 +87,7 @@ __global__ __launch_bounds__(192) void ep_block_kernel(int n, int np, int i0, in
                                                        double *__restrict__ tau, double *__restrict__ nu,
                                                        double *__restrict__ cav_tau, double *__restrict__ cav_nu,
                                                        double *__restrict__ cvec, double *__restrict__ ncoef,
-                                                       double *__restrict__ Lmat) {
+                                                       double *__restrict__ Lmat, double *__restrict__ Ldinv) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     constexpr int LS = GP_NB + 1;
     double *A = sm;                  // column c: Sigma0[blk, i0+c] until site c is processed, afterwards s_c[blk]
@@ -243,21 +254,72 @@ __global__ __launch_bounds__(192) void ep_block_kernel(int n, int np, int i0, in
         for (int c = 0; c < GP_NB; ++c)
             Lmat[r + (size_t)c * GP_NB] = (r == c) ? 1.0 : ((r > c && c < bsz) ? Sb[r + c * LS] * cs[c] : 0.0);
     }
+    // inverses of Lmat's eight 16 x 16 diagonal tiles (unit lower), the form the row-panel solve consumes (tile q at
+    // Ldinv + 256 q, element (c, k) at c + 16 k): forward substitution against the identity, here instead of in a launch of
+    // its own between the block kernel and the solve.  Wave 2 (idle while the row threads write Lmat) takes four tiles at a
+    // time, 16 lanes per tile, column owner = lane & 15; L(rr, k) comes back as an LDS broadcast within each 16-lane group.
+    if (!rowthread) {
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+            const int c0 = 16 * (4 * half + fg);
+            double x[16];
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) {
+                double sacc = (rr == fr) ? 1.0 : 0.0;
+#pragma unroll
+                for (int k = 0; k < rr; ++k) {
+                    const double lrk = (c0 + k < bsz) ? Sb[(c0 + rr) + (c0 + k) * LS] * cs[c0 + k] : 0.0;
+                    sacc = fma(-lrk, x[k], sacc);
+                }
+                x[rr] = sacc;   // unit diagonal
+            }
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) Ldinv[(c0 / 16) * 256 + rr + 16 * fr] = x[rr];
+        }
+    }
 }
 
-__global__ void scale_cols_kernel(double *__restrict__ dst, const double *__restrict__ src, const double *__restrict__ c, int rows, int cols, int ld) {
+// D (128 x 128, lower triangle, leading dimension ldd) -= Sc St^T with Sc, St the 128 x 128 row blocks (leading dimension ld)
+// of the scaled and unscaled delayed columns: the ONE tile of a block's rank-128 update that the next block kernel reads.
+// It sits on the serial chain of the sweep, where the general 128 x 128-tile GEMM would run it on a single CU (14 us of
+// MFMA issue alone); here its 36 lower 16 x 16 tiles go to 36 one-wave workgroups with the operands straight from L2.
+__global__ __launch_bounds__(64) void ep_diag_update_kernel(double *__restrict__ D, int ldd, const double *__restrict__ Sc,
+                                                            const double *__restrict__ St, int ld) {
+    int I = 0;
+    const int q = blockIdx.x;
+    while ((I + 1) * (I + 2) / 2 <= q) ++I;
+    const int J = q - I * (I + 1) / 2;
+    const int lane = threadIdx.x, fr = lane & 15, fg = lane >> 4;
+    double a[32], b[32];
+#pragma unroll
+    for (int ks = 0; ks < 32; ++ks) {
+        a[ks] = -Sc[(16 * J + fr) + (size_t)(4 * ks + fg) * ld];
+        b[ks] = St[(16 * I + fr) + (size_t)(4 * ks + fg) * ld];
+    }
+    double4_t acc;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) acc[rr] = D[(16 * I + fr) + (size_t)(16 * J + fg + 4 * rr) * ldd];
+#pragma unroll
+    for (int ks = 0; ks < 32; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[ks], acc, 0, 0, 0);
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr)
+        if (16 * I + fr >= 16 * J + fg + 4 * rr) D[(16 * I + fr) + (size_t)(16 * J + fg + 4 * rr) * ldd] = acc[rr];
+}
+
+__global__ void scale_cols_kernel(double *__restrict__ dst, int ldd, const double *__restrict__ src, int lds, const double *__restrict__ c,
+                                  int rows, int cols) {
     size_t total = (size_t)rows * cols;
     for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
         int i = (int)(e % rows), j = (int)(e / rows);
-        dst[i + (size_t)j * ld] = src[i + (size_t)j * ld] * c[j];
+        dst[i + (size_t)j * ldd] = src[i + (size_t)j * lds] * c[j];
     }
 }
 
 // B = I + (st st^T) o K on the lower triangle (EpParameterEstimator.scala:56-58); pad rows have st = 0
-__global__ void ep_bmat_kernel(double *__restrict__ B, const double *__restrict__ K, const double *__restrict__ st, int np) {
+__global__ void ep_bmat_kernel(double *__restrict__ B, int ldb, const double *__restrict__ K, const double *__restrict__ st, int np) {
     for (int j = blockIdx.y; j < np; j += gridDim.y)
         for (int i = j + blockIdx.x * blockDim.x + threadIdx.x; i < np; i += gridDim.x * blockDim.x)
-            B[i + (size_t)j * np] = (i == j ? 1.0 : 0.0) + (st[i] * st[j]) * K[i + (size_t)j * np];
+            B[i + (size_t)j * ldb] = (i == j ? 1.0 : 0.0) + (st[i] * st[j]) * K[i + (size_t)j * np];
 }
 
 __global__ void mirror_lower_kernel(double *__restrict__ A, int np) {
@@ -310,7 +372,7 @@ __global__ void ep_prob_kernel(double *__restrict__ prob, const double *__restri
 }
 
 // EP log marginal likelihood (EpParameterEstimator.scala:71-96); strict: the fourth/first term is dropped as compiled
-__global__ __launch_bounds__(1024) void ep_lml_kernel(int n, int np, const double *__restrict__ L, const double *__restrict__ tau,
+__global__ __launch_bounds__(1024) void ep_lml_kernel(int n, int ldl, const double *__restrict__ L, const double *__restrict__ tau,
                                                       const double *__restrict__ nu, const double *__restrict__ mu,
                                                       const double *__restrict__ cav_tau, const double *__restrict__ cav_nu,
                                                       const int *__restrict__ y, int strict, double *__restrict__ out) {
@@ -319,7 +381,7 @@ __global__ __launch_bounds__(1024) void ep_lml_kernel(int n, int np, const doubl
     for (int i = threadIdx.x; i < n; i += 1024) {
         const double ct = cav_tau[i], cm = cav_nu[i] / ct, T = tau[i] + ct;
         double third = log(pnorm_d(y[i] * cm / sqrt(1.0 + 1.0 / ct)));
-        double fourth = strict ? 0.0 : 0.5 * log(1.0 + tau[i] / ct) - log(L[i + (size_t)i * np]);
+        double fourth = strict ? 0.0 : 0.5 * log(1.0 + tau[i] / ct) - log(L[i + (size_t)i * ldl]);
         // 0.5 * [ nu^T (Sigma - diag(1/T)) nu + sum (cm ct / T)(tau cm - 2 nu) ],  nu^T Sigma nu = nu . mu
         double first = nu[i] * mu[i] - nu[i] * nu[i] / T;
         double second = ((cm * ct) * (1.0 / T)) * (tau[i] * cm - nu[i] * 2.0);
@@ -337,30 +399,102 @@ __global__ __launch_bounds__(1024) void ep_lml_kernel(int n, int np, const doubl
 constexpr int EP_BLOCK_LDS = (GP_NB * (GP_NB + 1) + 6 * GP_NB + 16) * (int)sizeof(double);
 inline dim3 g1(int n) { return dim3((n + 255) / 256); }
 
+// out[i] = sum_j A(i,j) x[j] for rows i in [lo, lo + m) of a SYMMETRIC n x n matrix of which only the lower triangle is stored
+// (mu = Sigma nu, EpParameterEstimator.scala:61, without mirroring Sigma first), in three small launches with a fixed
+// summation order:  row part  sum_{j <= i} A(i,j) x[j]  (thread = row, coalesced over i, the j range cut into SYMV_CHUNKS
+// chunks -> partial[chunk][i]);  column part  sum_{j > i} A(j,i) x[j]  (one wave per column, lanes striding the rows ->
+// partial[SYMV_CHUNKS][i]);  then the chunks are added in order.
+constexpr int SYMV_CHUNKS = 16;
+__global__ __launch_bounds__(256) void ep_symv_rows_kernel(const double *__restrict__ A, int ld, int n, const double *__restrict__ x,
+                                                           double *__restrict__ partial, int lo, int m) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= m) return;
+    const int i = lo + r, per = (n + SYMV_CHUNKS - 1) / SYMV_CHUNKS;
+    const int j0 = blockIdx.y * per, j1 = min(min(n, j0 + per), i + 1);
+    double acc = 0.0;
+#pragma unroll 8
+    for (int j = j0; j < j1; ++j) acc = fma(A[i + (size_t)j * ld], x[j], acc);
+    partial[(size_t)blockIdx.y * n + i] = acc;
+}
+__global__ __launch_bounds__(256) void ep_symv_cols_kernel(const double *__restrict__ A, int ld, int n, const double *__restrict__ x,
+                                                           double *__restrict__ partial, int lo, int m) {
+    const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= m) return;
+    const int c = lo + r;
+    double p0 = 0.0, p1 = 0.0;
+    int j = c + 1 + lane;
+    for (; j + 64 < n; j += 128) {
+        p0 = fma(A[j + (size_t)c * ld], x[j], p0);
+        p1 = fma(A[j + 64 + (size_t)c * ld], x[j + 64], p1);
+    }
+    if (j < n) p0 = fma(A[j + (size_t)c * ld], x[j], p0);
+    double pr = p0 + p1;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) pr += __shfl_xor(pr, o);
+    if (lane == 0) partial[(size_t)SYMV_CHUNKS * n + c] = pr;
+}
+__global__ void ep_symv_sum_kernel(const double *__restrict__ partial, int n, double *__restrict__ out, int lo, int m) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= m) return;
+    const int i = lo + r;
+    double acc = 0.0;
+    for (int c = 0; c <= SYMV_CHUNKS; ++c) acc += partial[(size_t)c * n + i];
+    out[i] = acc;
+}
+void ep_symv_lower(hipStream_t s, const double *A, int ld, int n, const double *x, double *partial, double *out, int lo, int m) {
+    hipLaunchKernelGGL(ep_symv_rows_kernel, dim3((m + 255) / 256, SYMV_CHUNKS), dim3(256), 0, s, A, ld, n, x, partial, lo, m);
+    hipLaunchKernelGGL(ep_symv_cols_kernel, dim3((m + 3) / 4), dim3(256), 0, s, A, ld, n, x, partial, lo, m);
+    hipLaunchKernelGGL(ep_symv_sum_kernel, dim3((m + 255) / 256), dim3(256), 0, s, partial, n, out, lo, m);
+}
+
 // end of sweep: L, Sigma, mu from the current site parameters (EpParameterEstimator.scala:56-61)
+//   B = I + S^1/2 K S^1/2 in rows [0, np) of ep->L, K S^1/2 in rows [np, 2 np): ONE blocked factorisation leaves L on top and
+//   Vt = (K S^1/2) L^-T below it (the extra rows ride through the panel solves and the trailing updates exactly like y^T does
+//   in the regression fit), so V = L \ (S^1/2 K) costs no separate chain of 2 np/128 launches;  Sigma = K - Vt Vt^T, lower
+//   triangle only (nothing in a sweep reads above the diagonal; gp_ep_get mirrors on demand), mu = Sigma nu from that triangle.
+//   The product is cut at column 512: the first 4 tile columns (all the next sweep's first blocks read) run on the main
+//   stream, the other (np/128 - 4)(np/128 - 3)/2 tiles -- one resident round at n = 4096 instead of 528 tiles = one round
+//   plus a 16-tile tail -- on the side stream, under the next sweep's first block kernels.  The side stream's work of the next
+//   sweep is queued behind it, and the main stream only reads beyond column 512 after it has waited for that work.
 gp_status ep_refactor(gp_ep *ep) {
     gp_ctx *ctx = ep->ctx;
-    hipStream_t s = ctx->stream;
-    const int n = ep->n, np = ep->np;
+    hipStream_t s = ctx->stream, s2 = ctx->side;
+    const int n = ep->n, np = ep->np, ldl = ep->ldl;
     hipLaunchKernelGGL(vec_sqrt_kernel, g1(np), dim3(256), 0, s, ep->st(), ep->tau(), n, np);
-    hipLaunchKernelGGL(ep_bmat_kernel, dim3(8, np < 65535 ? np : 65535), dim3(256), 0, s, ep->L, ep->K, ep->st(), np);
-    gpi_chol_blocked(ctx, ep->L, np, np, ep->dinv, 0);   // strict upper triangle of ep->L stays zero from allocation
-    // Vt = (K S^1/2) L^-T  (= V^T, V = L \ (S^1/2 K)); kept in the workspace
-    double *Vt;
-    GP_TRY(gpi_ws_get(ctx, WS_VT, sizeof(double) * (size_t)np * np, &Vt));
-    hipLaunchKernelGGL(scale_cols_kernel, dim3(2048), dim3(256), 0, s, Vt, ep->K, ep->st(), np, np, np);
-    gpi_solve_rows_lower(ctx, Vt, np, ep->L, np, np, ep->dinv, nullptr, nullptr, nullptr);
-    // Sigma = K - Vt Vt^T  (lower on the MFMA syrk, then mirrored)
-    gpk_copy_2d(s, ep->Sig, np, ep->K, np, np, np);
+    hipLaunchKernelGGL(ep_bmat_kernel, dim3(8, np < 65535 ? np : 65535), dim3(256), 0, s, ep->L, ldl, ep->K, ep->st(), np);
+    double *Vt = ep->L + np;
+    hipLaunchKernelGGL(scale_cols_kernel, dim3(2048), dim3(256), 0, s, Vt, ldl, ep->K, np, ep->st(), np, np);
+    gpi_chol_blocked(ctx, ep->L, np, ldl, ep->dinv, np);   // strict upper triangle of the top block stays zero from allocation
+    const bool split = np > 1024 && [] { const char *e = getenv("GPCORE_EP_OVERLAP"); return !e || atoi(e) != 0; }();
+    const int c1 = split ? 512 : np;
     gp_prof_begin(ctx, GP_PROF_SYRK);
-    gpk_gemm_nt(s, np, np, np, -1.0, Vt, np, Vt, np, 1.0, ep->Sig, np, 1);
-    gp_prof_end(ctx, GP_PROF_SYRK, (double)np * np * np);
-    hipLaunchKernelGGL(mirror_lower_kernel, dim3(np / 64, np / 64), dim3(256), 0, s, ep->Sig, np);
-    hipLaunchKernelGGL(mirror_diag_kernel, dim3(np / 64), dim3(256), 0, s, ep->Sig, np);
-    // mu = Sigma nu
-    double *partial;
-    GP_TRY(gpi_ws_get(ctx, WS_PARTIAL, sizeof(double) * (size_t)16 * np, &partial));
-    gpk_gemv_rows(s, ep->Sig, n, n, np, ep->nu(), ep->mu(), partial, 16);
+    gpk_gemm_nt(s, np, c1, np, -1.0, Vt, ldl, Vt, ldl, 1.0, ep->Sig, np, 1, 0, gp_batch(), ep->K, np);
+    gp_prof_end(ctx, GP_PROF_SYRK, 2.0 * GP_NB * GP_NB * np * ((double)(np / GP_NB) * (c1 / GP_NB) - (double)(c1 / GP_NB) * (c1 / GP_NB - 1) / 2.0));
+    double *partial;   // rows of the two parts are disjoint, so both streams may use it at once
+    GP_TRY(gpi_ws_get(ctx, WS_PARTIAL, sizeof(double) * (size_t)(SYMV_CHUNKS + 1) * np, &partial));
+    ep_symv_lower(s, ep->Sig, np, np, ep->nu(), partial, ep->mu(), 0, c1);
+    if (split) {
+        const int r = np - c1;
+        // the second part starts when the first is done: started together, the two launches share the chip and the columns the
+        // next sweep needs first arrive last
+        GP_HIP(ctx, hipEventRecord(ep->ev_parta, s));
+        GP_HIP(ctx, hipStreamWaitEvent(s2, ep->ev_parta, 0));
+        gp_prof_begin(ctx, GP_PROF_SYRK, s2);
+        gpk_gemm_nt(s2, r, r, np, -1.0, Vt + c1, ldl, Vt + c1, ldl, 1.0, ep->Sig + (size_t)c1 + (size_t)c1 * np, np, 1, 0, gp_batch(),
+                    ep->K + (size_t)c1 + (size_t)c1 * np, np);
+        gp_prof_end(ctx, GP_PROF_SYRK, 2.0 * GP_NB * GP_NB * np * ((double)(r / GP_NB) * (r / GP_NB + 1) / 2.0), s2);
+        ep_symv_lower(s2, ep->Sig, np, np, ep->nu(), partial, ep->mu(), c1, r);   // rows >= 512 of mu also read the first 512 columns
+        GP_HIP(ctx, hipEventRecord(ep->ev_partb, s2));
+        ep->side_pending = true;
+    }
+    ep->sig_mirrored = false;
+    return GP_OK;
+}
+
+// everything the side stream still owes (second part of Sigma and mu) is ordered before whatever the main stream does next
+gp_status ep_join_side(gp_ep *ep) {
+    if (ep->side_pending) GP_HIP(ep->ctx, hipStreamWaitEvent(ep->ctx->stream, ep->ev_partb, 0));
+    ep->side_pending = false;
     return GP_OK;
 }
 
@@ -372,21 +506,27 @@ gp_status ep_alloc(gp_ctx *ctx, int n, const int32_t *y, gp_ep **out) {
     GP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(ep_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, EP_BLOCK_LDS));
     gp_ep *ep = new (std::nothrow) gp_ep();
     if (!ep) return GP_ENOMEM;
-    ep->ctx = ctx; ep->n = n; ep->np = gp_pad(n);
+    ep->ctx = ctx; ep->n = n; ep->np = gp_pad(n); ep->ldl = 2 * ep->np;
     const size_t np = ep->np, nn = np * np * sizeof(double);
     hipError_t e = hipMalloc(&ep->K, nn);
     if (e == hipSuccess) e = hipMalloc(&ep->Sig, nn);
-    if (e == hipSuccess) e = hipMalloc(&ep->L, nn);
+    if (e == hipSuccess) e = hipMalloc(&ep->L, 2 * nn);
     if (e == hipSuccess) e = hipMalloc(&ep->dinv, np * 16 * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&ep->S, np * GP_NB * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&ep->Sc, np * GP_NB * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc(&ep->blk, (GP_NB * GP_NB + 8 * 256) * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&ep->blk, 2 * (GP_NB * GP_NB + 8 * 256) * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&ep->vec, 10 * np * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc(&ep->cvec, 2 * GP_NB * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&ep->cvec, 4 * GP_NB * sizeof(double));
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ep->ev_chol, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ep->ev_parta, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ep->ev_partb, hipEventDisableTiming);
+    ep->ev.assign(3 * (np / GP_NB), nullptr);
+    for (hipEvent_t &ev : ep->ev)
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc(&ep->y, np * sizeof(int));
     hipStream_t s = ctx->stream;
     if (e == hipSuccess) e = hipMemsetAsync(ep->K, 0, nn, s);
-    if (e == hipSuccess) e = hipMemsetAsync(ep->L, 0, nn, s);
+    if (e == hipSuccess) e = hipMemsetAsync(ep->L, 0, 2 * nn, s);
     if (e == hipSuccess) e = hipMemsetAsync(ep->y, 0, np * sizeof(int), s);
     if (e == hipSuccess) e = hipMemcpyAsync(ep->y, y, n * sizeof(int), hipMemcpyHostToDevice, s);
     if (e != hipSuccess) { GP_SET_ERR(ctx, "EP allocation (n=%d) failed: %s", n, hipGetErrorString(e)); gp_ep_destroy(ep); return GP_ENOMEM; }
@@ -399,9 +539,11 @@ gp_status ep_start(gp_ep *ep) {
     gp_ctx *ctx = ep->ctx;
     hipStream_t s = ctx->stream;
     GP_HIP(ctx, hipMemsetAsync(ep->vec, 0, 10 * (size_t)ep->np * sizeof(double), s));
-    GP_HIP(ctx, hipMemsetAsync(ep->cvec, 0, 2 * GP_NB * sizeof(double), s));
+    GP_HIP(ctx, hipMemsetAsync(ep->cvec, 0, 4 * GP_NB * sizeof(double), s));
     gpk_pad_identity(s, ep->K, ep->n, ep->np, ep->np);
     gpk_copy_2d(s, ep->Sig, ep->np, ep->K, ep->np, ep->np, ep->np);   // sigmaMatrix = kernelMatrix.copy (:35)
+    ep->sig_mirrored = true;
+    ep->side_pending = false;
     ep->sweeps = 0;
     GP_HIP(ctx, hipStreamSynchronize(s));
     return GP_OK;
@@ -434,35 +576,75 @@ gp_status gp_ep_sweep(gp_ep *ep, int nsweeps, double *tau, double *nu, int *info
     const int n = ep->n, np = ep->np;
     if (info) *info = 0;
     GP_HIP(ctx, hipMemsetAsync(ctx->d_info, 0, sizeof(int), s));
+    // GPCORE_EP_OVERLAP=0: every launch of a site block on one stream (the form the overlapped one is tested against)
+    const bool overlap = [] { const char *e = getenv("GPCORE_EP_OVERLAP"); return !e || atoi(e) != 0; }();
+    hipStream_t s2 = ctx->side;
     for (int sw = 0; sw < nsweeps; ++sw) {
-        for (int i0 = 0; i0 < n; i0 += GP_NB) {
+        // Only the TRAILING part of the recurrence is carried: the sites after a block read mu_i and Sigma_ii "as of now",
+        // which depend on the earlier blocks through rows/columns >= their own block only, and the end-of-sweep
+        // refactorisation (:56-61) rebuilds Sigma and mu from the site parameters anyway.  So the delayed columns
+        // S = Sigma0[r0:, blk] Lmat^-T, the mean update mu[r0:] += S coef and the rank-128 update
+        // Sigma[r0:, r0:] -= S diag(c) S^T cover rows/columns r0 = i0 + 128 onwards (lower triangle) -- n^3/3 flops per
+        // sweep on the MFMA syrk instead of 2 n^3 on full-square updates.  The block's own column panel of Sigma is dead after
+        // the block, so the panel solve runs in place on it; the same launch writes the scaled copy S diag(c) and adds S coef
+        // to the mean (row dot fused into the panel solve).
+        //
+        // Two streams.  The serial chain -- block kernel b (one workgroup, ~110 us) -> the 128 rows of S that belong to block
+        // b+1 -> the ONE 128 x 128 tile of the update block kernel b+1 reads -> block kernel b+1 -- stays on the main stream;
+        // the rest of block b's panel solve and rank-128 update (all rows from block b+2 on) runs on the side stream UNDER block
+        // kernel b+1.  The side stream is CU-masked (gp_ctx_create), so the block kernel, which needs most of a CU's LDS,
+        // always finds a free CU.  Small per-block buffers (Lmat, tile inverses, c, coef) alternate by block parity: the
+        // side stream still reads block b's while block kernel b+1 writes its own.
+        int b = 0;
+        hipEvent_t last_side = nullptr;
+        for (int i0 = 0; i0 < n; i0 += GP_NB, ++b) {
             const int bsz = (n - i0 < GP_NB) ? n - i0 : GP_NB;
-            double *Lmat = ep->blk, *bdinv = ep->blk + GP_NB * GP_NB;
-            double *ncoef = ep->cvec + GP_NB;   // + coef of every site of the block
+            const int par = b & 1;
+            double *Lmat = ep->blk + (size_t)par * (GP_NB * GP_NB + 8 * 256), *bdinv = Lmat + GP_NB * GP_NB;
+            double *cvec = ep->cvec + (size_t)par * 2 * GP_NB, *ncoef = cvec + GP_NB;   // c and coef of every site of the block
             hipLaunchKernelGGL(ep_block_kernel, dim3(1), dim3(192), EP_BLOCK_LDS, s, n, np, i0, bsz, ep->Sig, ep->mu(), ep->y,
-                               ep->tau(), ep->nu(), ep->cav_tau(), ep->cav_nu(), ep->cvec, ncoef, Lmat);
-            // Only the TRAILING part of the recurrence is carried: the sites after this block read mu_i and Sigma_ii "as of
-            // now", which depend on the earlier blocks through rows/columns >= their own block only, and the end-of-sweep
-            // refactorisation (:56-61) rebuilds Sigma and mu from the site parameters anyway.  So the delayed columns
-            // S = Sigma0[r0:, blk] Lmat^-T, the mean update mu[r0:] += S coef and the rank-128 update
-            // Sigma[r0:, r0:] -= S diag(c) S^T cover rows/columns r0 = i0 + 128 onwards (lower triangle: the block kernel mirrors
-            // its diagonal block on load) -- n^3/3 flops per sweep on the MFMA syrk instead of 2 n^3 on full-square updates.
+                               ep->tau(), ep->nu(), ep->cav_tau(), ep->cav_nu(), cvec, ncoef, Lmat, bdinv);
             const int r0 = i0 + GP_NB, rt = np - r0;
-            if (rt > 0 && r0 < n) {
-                // the block's own column panel of Sigma is dead after this block, so it is solved in place; the same launch
-                // writes the scaled copy S diag(c) and adds S coef to the mean (row dot fused into the panel solve)
-                double *St = ep->Sig + (size_t)r0 + (size_t)i0 * np, *Sct = ep->Sc + r0;
-                gpk_tile_inverses(s, Lmat, GP_NB, GP_NB, bdinv);
-                gpk_trsm_panel128(s, St, rt, np, Lmat, GP_NB, bdinv, nullptr, ncoef, ep->mu() + r0, gp_batch(), Sct, ep->cvec);
+            if (rt <= 0 || r0 >= n) continue;
+            double *St = ep->Sig + (size_t)r0 + (size_t)i0 * np, *Sct = ep->Sc + r0;
+            double *Ctr = ep->Sig + (size_t)r0 + (size_t)r0 * np;
+            if (!overlap) {
+                gpk_trsm_panel128(s, St, rt, np, Lmat, GP_NB, bdinv, nullptr, ncoef, ep->mu() + r0, gp_batch(), Sct, cvec);
                 gp_prof_begin(ctx, GP_PROF_GEMM);
-                gpk_gemm_nt(s, rt, rt, GP_NB, -1.0, Sct, np, St, np, 1.0, ep->Sig + (size_t)r0 + (size_t)r0 * np, np, 1);
+                gpk_gemm_nt(s, rt, rt, GP_NB, -1.0, Sct, np, St, np, 1.0, Ctr, np, 1);
                 gp_prof_end(ctx, GP_PROF_GEMM, (double)rt * ((double)rt + GP_NB) * GP_NB);
+                continue;
             }
+            hipEvent_t ev_fac = ep->ev[3 * b], ev_rows = ep->ev[3 * b + 1], ev_side = ep->ev[3 * b + 2];
+            const int rest = rt - GP_NB;            // rows from block b+2 on
+            if (rest > 0) {
+                GP_HIP(ctx, hipEventRecord(ev_fac, s));
+                GP_HIP(ctx, hipStreamWaitEvent(s2, ev_fac, 0));
+                // side stream, part 1: rows [r0+128, np) of the panel solve and their own lower triangle of the update
+                gpk_trsm_panel128(s2, St + GP_NB, rest, np, Lmat, GP_NB, bdinv, nullptr, ncoef, ep->mu() + r0 + GP_NB, gp_batch(), Sct + GP_NB, cvec);
+                gp_prof_begin(ctx, GP_PROF_GEMM, s2);
+                gpk_gemm_nt(s2, rest, rest, GP_NB, -1.0, Sct + GP_NB, np, St + GP_NB, np, 1.0, Ctr + GP_NB + (size_t)GP_NB * np, np, 1);
+                gp_prof_end(ctx, GP_PROF_GEMM, (double)rest * ((double)rest + GP_NB) * GP_NB, s2);
+            }
+            // main stream: the 128 rows of block b+1 -- they read Sigma entries the side stream's update of block b-1 wrote
+            if (b > 0) GP_HIP(ctx, hipStreamWaitEvent(s, ep->ev[3 * (b - 1) + 2], 0));
+            gpk_trsm_panel128(s, St, GP_NB, np, Lmat, GP_NB, bdinv, nullptr, ncoef, ep->mu() + r0, gp_batch(), Sct, cvec);
+            hipLaunchKernelGGL(ep_diag_update_kernel, dim3(36), dim3(64), 0, s, Ctr, np, Sct, St, np);
+            if (rest > 0) {
+                GP_HIP(ctx, hipEventRecord(ev_rows, s));
+                GP_HIP(ctx, hipStreamWaitEvent(s2, ev_rows, 0));
+                // side stream, part 2: column panel of block b+1 below its diagonal tile (needs the rows the main stream just solved)
+                gpk_gemm_nt(s2, rest, GP_NB, GP_NB, -1.0, Sct + GP_NB, np, St, np, 1.0, Ctr + GP_NB, np, 0);
+            }
+            GP_HIP(ctx, hipEventRecord(ev_side, s2));
+            last_side = ev_side;
         }
+        if (last_side) GP_HIP(ctx, hipStreamWaitEvent(s, last_side, 0));   // the refactorisation rewrites Sigma and mu
         GP_TRY(ep_refactor(ep));
         GP_LAUNCH_CHECK(ctx);
         ep->sweeps += 1;
     }
+    GP_TRY(ep_join_side(ep));
     int h = 0;
     GP_TRY(gpi_read_info(ctx, &h));
     if (info) *info = h;
@@ -482,6 +664,7 @@ gp_status gp_ep_set_site_params(gp_ep *ep, const double *tau, const double *nu, 
     GP_TRY(gpi_upload_2d(ctx, ep->tau(), ep->np, tau, ep->n, ep->n, 1));
     GP_TRY(gpi_upload_2d(ctx, ep->nu(), ep->np, nu, ep->n, ep->n, 1));
     GP_TRY(ep_refactor(ep));
+    GP_TRY(ep_join_side(ep));
     int h = 0;
     GP_TRY(gpi_read_info(ctx, &h));
     if (info) *info = h;
@@ -495,7 +678,7 @@ gp_status gp_ep_lml(gp_ep *ep, int strict, double *lml) {
     gp_ctx *ctx = ep->ctx;
     GP_REQUIRE(ctx, ep->sweeps > 0, "no sweep has run yet");
     GP_HIP(ctx, hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(ep_lml_kernel, dim3(1), dim3(1024), 0, ctx->stream, ep->n, ep->np, ep->L, ep->tau(), ep->nu(), ep->mu(),
+    hipLaunchKernelGGL(ep_lml_kernel, dim3(1), dim3(1024), 0, ctx->stream, ep->n, ep->ldl, ep->L, ep->tau(), ep->nu(), ep->mu(),
                        ep->cav_tau(), ep->cav_nu(), ep->y, strict, ctx->d_scalars);
     return gpi_download_2d(ctx, lml, 1, ctx->d_scalars, 1, 1, 1);
 }
@@ -521,19 +704,19 @@ gp_status gp_ep_lml_grad_rbf(gp_ep *ep, const double *X, int d, int ldx, const d
     hipLaunchKernelGGL(vec_mul_kernel, g1(n), dim3(256), 0, s, t1, t1, ep->st(), n);
     const double *Kinv = nullptr;
     if (strict) {
-        gpi_back_solve_vec(ctx, ep->L, np, np, ep->dinv, t1, t2);                       // temp = L^T \ rhs           :53
+        gpi_back_solve_vec(ctx, ep->L, np, ep->ldl, ep->dinv, t1, t2);                       // temp = L^T \ rhs           :53
         hipLaunchKernelGGL(vec_div_kernel, g1(n), dim3(256), 0, s, t2, t2, ep->st(), n);   // (S^1/2 L) x = temp  <=>  L x = temp / st
-        gpi_forward_solve_vec(ctx, ep->L, np, np, ep->dinv, t2, t1);                    //                              :55-56
+        gpi_forward_solve_vec(ctx, ep->L, np, ep->ldl, ep->dinv, t2, t1);                    //                              :55-56
         hipLaunchKernelGGL(vec_sub_kernel, g1(np), dim3(256), 0, s, t2, ep->nu(), t1, n, np);   // b = nu - x
     } else {
-        gpi_forward_solve_vec(ctx, ep->L, np, np, ep->dinv, t1, t2);
-        gpi_back_solve_vec(ctx, ep->L, np, np, ep->dinv, t2, t1);
+        gpi_forward_solve_vec(ctx, ep->L, np, ep->ldl, ep->dinv, t1, t2);
+        gpi_back_solve_vec(ctx, ep->L, np, ep->ldl, ep->dinv, t2, t1);
         hipLaunchKernelGGL(ep_w_kernel, g1(np), dim3(256), 0, s, t2, ep->nu(), ep->st(), t1, n, np);    // b = nu - st o z
         // R = b b^T - S^1/2 (L L^T)^-1 S^1/2 :  (L L^T)^-1 = T T^T with T = L^-T
         double *T, *Binv;
         GP_TRY(gpi_ws_get(ctx, WS_VT, sizeof(double) * (size_t)np * np, &T));
         GP_TRY(gpi_ws_get(ctx, WS_D, sizeof(double) * (size_t)np * np, &Binv));
-        gpi_inverse_transpose_lower(ctx, T, ep->L, np, np, ep->dinv);
+        gpi_inverse_transpose_lower(ctx, T, ep->L, np, ep->ldl, ep->dinv);
         gpk_gemm_nt(s, np, np, np, 1.0, T, np, T, np, 0.0, Binv, np, 1, 1);
         hipLaunchKernelGGL(scale_sym_lower_kernel, dim3(8, n < 65535 ? n : 65535), dim3(256), 0, s, Binv, ep->st(), n, np);
         Kinv = Binv;
@@ -548,8 +731,15 @@ gp_status gp_ep_get(gp_ep *ep, int what, double *out, int ld) {
     const int n = ep->n, np = ep->np;
     GP_HIP(ctx, hipSetDevice(ctx->device));
     switch (what) {
-        case GP_EP_GET_L: GP_REQUIRE(ctx, ld >= n, "ld < n"); return gpi_download_2d(ctx, out, ld, ep->L, np, n, n);
-        case GP_EP_GET_SIGMA: GP_REQUIRE(ctx, ld >= n, "ld < n"); return gpi_download_2d(ctx, out, ld, ep->Sig, np, n, n);
+        case GP_EP_GET_L: GP_REQUIRE(ctx, ld >= n, "ld < n"); return gpi_download_2d(ctx, out, ld, ep->L, ep->ldl, n, n);
+        case GP_EP_GET_SIGMA:
+            GP_REQUIRE(ctx, ld >= n, "ld < n");
+            if (!ep->sig_mirrored) {   // a sweep keeps the lower triangle only
+                hipLaunchKernelGGL(mirror_lower_kernel, dim3(np / 64, np / 64), dim3(256), 0, ctx->stream, ep->Sig, np);
+                hipLaunchKernelGGL(mirror_diag_kernel, dim3(np / 64), dim3(256), 0, ctx->stream, ep->Sig, np);
+                ep->sig_mirrored = true;
+            }
+            return gpi_download_2d(ctx, out, ld, ep->Sig, np, n, n);
         case GP_EP_GET_MU: return gpi_download_2d(ctx, out, n, ep->mu(), np, n, 1);
         case GP_EP_GET_CAV_TAU: return gpi_download_2d(ctx, out, n, ep->cav_tau(), np, n, 1);
         case GP_EP_GET_CAV_NU: return gpi_download_2d(ctx, out, n, ep->cav_nu(), np, n, 1);
@@ -575,17 +765,17 @@ gp_status gp_ep_predict(gp_ep *ep, const double *Ks, int m, int ldks, const doub
     // z = st o L^T \ (L \ (st o (K nu)))                                  GpClassifier.scala:33-36
     gpk_gemv_rows(s, ep->K, n, n, np, ep->nu(), ep->tmp1(), partial, 16);
     hipLaunchKernelGGL(vec_mul_kernel, g1(n), dim3(256), 0, s, ep->tmp1(), ep->tmp1(), ep->st(), n);
-    gpi_forward_solve_vec(ctx, ep->L, np, np, ep->dinv, ep->tmp1(), ep->tmp2());
-    gpi_back_solve_vec(ctx, ep->L, np, np, ep->dinv, ep->tmp2(), ep->tmp1());
+    gpi_forward_solve_vec(ctx, ep->L, np, ep->ldl, ep->dinv, ep->tmp1(), ep->tmp2());
+    gpi_back_solve_vec(ctx, ep->L, np, ep->ldl, ep->dinv, ep->tmp2(), ep->tmp1());
     hipLaunchKernelGGL(ep_w_kernel, g1(np), dim3(256), 0, s, ep->tmp2(), ep->nu(), ep->st(), ep->tmp1(), n, np);   // w = nu - z
     // test-train block: fMean = K* w; V = L \ (st o K*^T) as rows; var = kss - |v|^2    :37-45
     GP_HIP(ctx, hipMemsetAsync(Vt, 0, sizeof(double) * (size_t)mp * np, s));
     GP_TRY(gpi_upload_2d(ctx, Vt, mp, Ks, ldks, m, n));
     GP_HIP(ctx, hipMemcpyAsync(dk, kss_diag, sizeof(double) * m, hipMemcpyHostToDevice, s));
     gpk_gemv_rows(s, Vt, m, n, mp, ep->tmp2(), dout, partial, 16);
-    hipLaunchKernelGGL(scale_cols_kernel, dim3(1024), dim3(256), 0, s, Vt, Vt, ep->st(), mp, np, mp);
+    hipLaunchKernelGGL(scale_cols_kernel, dim3(1024), dim3(256), 0, s, Vt, mp, Vt, mp, ep->st(), mp, np);
     GP_HIP(ctx, hipMemsetAsync(sumsq, 0, sizeof(double) * mp, s));
-    gpi_solve_rows_lower(ctx, Vt, mp, ep->L, np, np, ep->dinv, sumsq, nullptr, nullptr);
+    gpi_solve_rows_lower(ctx, Vt, mp, ep->L, np, ep->ldl, ep->dinv, sumsq, nullptr, nullptr);
     hipLaunchKernelGGL(ep_prob_kernel, g1(m), dim3(256), 0, s, dout + mp, dout, sumsq, dk, m);
     return gpi_download_2d(ctx, prob, m, dout + mp, m, m, 1);
 }
@@ -672,6 +862,8 @@ gp_status gp_ep_lml_rbf_batched(gp_ctx *ctx, const double *X, int n, int d, int 
 void gp_ep_destroy(gp_ep *ep) {
     if (!ep) return;
     if (ep->ctx) { (void)hipSetDevice(ep->ctx->device); (void)hipStreamSynchronize(ep->ctx->stream); }
+    for (hipEvent_t ev : ep->ev) if (ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : {ep->ev_chol, ep->ev_parta, ep->ev_partb}) if (ev) (void)hipEventDestroy(ev);
     void *ptrs[] = {ep->K, ep->Sig, ep->L, ep->dinv, ep->S, ep->Sc, ep->blk, ep->vec, ep->cvec, ep->y};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete ep;

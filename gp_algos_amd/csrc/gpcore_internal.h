@@ -92,7 +92,8 @@ struct gp_batch {
 // lower != 0: M >= N, only tiles on/below the diagonal (bi >= bj) are computed; on diagonal tiles only i >= j is stored.
 // ktri != 0: A(i,k) is zero for k < i (upper-triangular operand): each tile starts its k loop at its row block.
 void gpk_gemm_nt(hipStream_t s, int M, int N, int K, double alpha, const double *A, int lda, const double *B, int ldb,
-                 double beta, double *C, int ldc, int lower, int ktri = 0, gp_batch bt = gp_batch());   // strides: A, B, C
+                 double beta, double *C, int ldc, int lower, int ktri = 0, gp_batch bt = gp_batch(),   // strides: A, B, C
+                 const double *Cin = nullptr, int ldcin = 0);   // beta term read from Cin instead of C (C = beta*Cin + alpha*A*B^T, single problem)
 // C[M x 128] = A[M x K] * B[128 x K]^T with fused row reductions (sumsq[m] += sum_n C(m,n)^2, dots[m] += sum_n C(m,n) tvec[n]);
 // C may be the last 128 columns of A (in-place posterior step).
 void gpk_gemm_nt_rowred(hipStream_t s, int M, int N, int K, const double *A, int lda, const double *B, int ldb, double *C, int ldc,

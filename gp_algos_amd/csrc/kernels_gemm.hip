@@ -70,7 +70,8 @@ struct gemm_rowred {
 template <int LOWER, int HAS_BETA, int NW, int RR = 0>
 __global__ __launch_bounds__(NW * 64, NW / 2) void gemm_nt_f64_kernel(int M, int N, int K, double alpha, const double *__restrict__ A, int lda,
                                                            const double *__restrict__ B, int ldb, double beta,
-                                                           double *__restrict__ C, int ldc, int ktri, gp_batch bt, gemm_rowred rr) {
+                                                           double *__restrict__ C, int ldc, int ktri, gp_batch bt, gemm_rowred rr,
+                                                           const double *__restrict__ Cin, int ldcin) {
     __shared__ __attribute__((aligned(16))) double smem[2 * 2 * TK * LDS_STRIDE];
     double *As = smem;                          // [2][TK][LDS_STRIDE]
     double *Bs = smem + 2 * TK * LDS_STRIDE;    // [2][TK][LDS_STRIDE]
@@ -111,6 +112,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void gemm_nt_f64_kernel(int M, int
     A += (size_t)prob * bt.s0;
     B += (size_t)prob * bt.s1;
     C += (size_t)prob * bt.s2;
+    if (!Cin) { Cin = C; ldcin = ldc; }   // the beta term is read from C itself unless the caller names another source (single problems only)
     const int row0 = bi * TM, col0 = bj * TN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int NT = (NW == 8) ? 2 : 4;          // 16-column accumulator tiles per wave (8 waves: 64 x 32 per wave)
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void gemm_nt_f64_kernel(int M, int
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) {
                     const int m = row0 + wm + mt * 16 + fr;
-                    cv[r][mt] = (diag_tile && m < n) ? 0.0 : C[m + (size_t)n * ldc];
+                    cv[r][mt] = (diag_tile && m < n) ? 0.0 : Cin[m + (size_t)n * ldcin];
                 }
             }
         }
@@ -400,7 +402,7 @@ __global__ __launch_bounds__(256) void mfma_probe_kernel(double *out, unsigned l
 }  // namespace
 
 void gpk_gemm_nt(hipStream_t s, int M, int N, int K, double alpha, const double *A, int lda, const double *B, int ldb,
-                 double beta, double *C, int ldc, int lower, int ktri, gp_batch bt) {
+                 double beta, double *C, int ldc, int lower, int ktri, gp_batch bt, const double *Cin, int ldcin) {
     if (M <= 0 || N <= 0 || bt.count <= 0) return;
     const gemm_rowred rr;
     const bool hb = beta != 0.0;
@@ -423,7 +425,7 @@ void gpk_gemm_nt(hipStream_t s, int M, int N, int K, double alpha, const double 
         ntiles = 8 * most;
         gy = 1;
     }
-#define GP_LAUNCH(LO, HB, NWV) hipLaunchKernelGGL((gemm_nt_f64_kernel<LO, HB, NWV>), dim3(ntiles, gy), dim3(NWV * 64), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, ktri, bt, rr)
+#define GP_LAUNCH(LO, HB, NWV) hipLaunchKernelGGL((gemm_nt_f64_kernel<LO, HB, NWV>), dim3(ntiles, gy), dim3(NWV * 64), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, ktri, bt, rr, Cin, ldcin)
     if (nw == 8) {
         if (lower) { if (hb) GP_LAUNCH(1, 1, 8); else GP_LAUNCH(1, 0, 8); }
         else { if (hb) GP_LAUNCH(0, 1, 8); else GP_LAUNCH(0, 0, 8); }
@@ -467,9 +469,9 @@ void gpk_gemm_nt_rowred(hipStream_t s, int M, int N, int K, const double *A, int
     rr.sumsq = sumsq, rr.tvec = tvec, rr.dots = dots;
     const int ntiles = (M / TM) * (N / TN);
     if (nw == 8)
-        hipLaunchKernelGGL((gemm_nt_f64_kernel<0, 0, 8, 1>), dim3(ntiles), dim3(512), 0, s, M, N, K, 1.0, A, lda, B, ldb, 0.0, C, ldc, 0, gp_batch(), rr);
+        hipLaunchKernelGGL((gemm_nt_f64_kernel<0, 0, 8, 1>), dim3(ntiles), dim3(512), 0, s, M, N, K, 1.0, A, lda, B, ldb, 0.0, C, ldc, 0, gp_batch(), rr, nullptr, 0);
     else
-        hipLaunchKernelGGL((gemm_nt_f64_kernel<0, 0, 4, 1>), dim3(ntiles), dim3(256), 0, s, M, N, K, 1.0, A, lda, B, ldb, 0.0, C, ldc, 0, gp_batch(), rr);
+        hipLaunchKernelGGL((gemm_nt_f64_kernel<0, 0, 4, 1>), dim3(ntiles), dim3(256), 0, s, M, N, K, 1.0, A, lda, B, ldb, 0.0, C, ldc, 0, gp_batch(), rr, nullptr, 0);
 }
 
 double gpk_probe_mfma(hipStream_t s, int num_cu, int waves_per_simd, double *clock_mhz, double *cycles_per_mfma) {
