@@ -28,27 +28,81 @@ PEAK_FP64_MFMA_TFLOPS = 78.6   # MI355X vendor fp64 matrix peak; 
 PEAK_HBM_GBS = 8000.0
 
 
-def cpu_baseline(p, L_host, alpha_host, budget_pts):
-    """Oracle (CPU restatement of the reference, 1 thread) timed on a bounded sample of the same workload."""
+def host_cores():
+    """Cores this process may really use: the affinity mask, cut by a cgroup CPU quota when there is one (the GPU box hands a
+    16-core share of a 256-thread host: spawning one BLAS thread per visible CPU only oversubscribes it)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("GPCORE_CPU_THREADS", "64"))))
+
+
+def cpu_baseline(p, L_host, alpha_host, m_total, budget_pts=256):
+    """The stated CPU baseline (`cpu_ref`): oracle/gp_oracle.c -- the 1-thread restatement of the reference's
+    loops -- timed on a BOUNDED sample of the same workload.  Fit (Gram + unblocked Cholesky + two substitution solves,
+    GpPredictor.preComputeComponents) is timed at n = 1024, 2048, 4096 on leading subsets of the same X, y and extrapolated
+    to the full n by a least-squares cubic a n^3 + b n^2 (n = 8192 itself would take minutes); predict (cross-Gram + scalar
+    forward substitution + variance per point) is timed at the full n against the real factor on a few of the test points.
+    value = points/s of a whole fit + predict step, the benchmark's metric."""
     from oracle import gp_oracle as orc
     orc.build()
+    n = p["X"].shape[0]
+    sizes = [s_ for s_ in (1024, 2048, 4096) if s_ <= n]
+    fit_s = []
+    for s_ in sizes:
+        Xs_, ys_ = np.asfortranarray(p["X"][:s_]), np.ascontiguousarray(p["y"][:s_])
+        t0 = time.perf_counter()
+        orc.fit(Xs_, ys_, p["theta"])
+        fit_s.append(time.perf_counter() - t0)
+    if sizes and sizes[-1] == n:
+        fit_full, extrapolated = fit_s[-1], False
+    else:
+        A = np.array([[float(s_) ** 3, float(s_) ** 2] for s_ in sizes])
+        coef, *_ = np.linalg.lstsq(A, np.array(fit_s), rcond=None)
+        fit_full, extrapolated = float(coef[0] * float(n) ** 3 + coef[1] * float(n) ** 2), True
     xs = np.asfortranarray(p["Xs"][:2])
     t0 = time.perf_counter()
     orc.predict(p["X"], p["theta"], L_host, alpha_host, xs)
     per_pt = (time.perf_counter() - t0) / 2
-    k = int(max(2, min(budget_pts, 15.0 / max(per_pt, 1e-6))))
+    k = int(max(2, min(budget_pts, 10.0 / max(per_pt, 1e-6))))
     xs = np.asfortranarray(p["Xs"][:k])
     t0 = time.perf_counter()
     mean, var, _, _ = orc.predict(p["X"], p["theta"], L_host, alpha_host, xs)
     dt = time.perf_counter() - t0
-    return dict(value=k / dt, unit="points/s", cores=1, kind="port",
-                sample="oracle/gp_oracle.c predict (cross-Gram + scalar forward substitution + variance) of %d of the "
-                       "%d test points against the n=%d factor; L and alpha taken from the GPU fit, CPU fit not timed "
-                       "(oracle dpotf2 at n=%d is minutes)" % (k, p["Xs"].shape[0], p["X"].shape[0], p["X"].shape[0])), mean, var, k
+    step_s = fit_full + m_total * dt / k
+    return dict(value=m_total / step_s, unit="points/s", cores=1, kind="port", extrapolated=extrapolated,
+                fit_s_measured={str(s_): t for s_, t in zip(sizes, fit_s)}, fit_s_at_n=fit_full, predict_points_per_s=k / dt,
+                step_s_at_n=step_s,
+                sample="oracle/gp_oracle.c, 1 thread: fit timed at n=%s on leading subsets of the same X, y and extrapolated to "
+                       "n=%d by a least-squares a*n^3+b*n^2; predict timed on %d of the %d test points at the full n=%d against the "
+                       "factor of the GPU fit; value = %d points / (fit + %d points at the measured rate)"
+                       % ("/".join(map(str, sizes)), n, k, m_total, n, m_total, m_total)), mean, var, k
+
+
+def _roofline_from_profile(ctx, L, classes, names):
+    """The kernel class that took the most stream time during the timed steps (HIP events recorded by the library around every
+    launch of that class, on the stream the launch went to): achieved = algorithmic flops of its launches / their summed time."""
+    best = None
+    for cls in classes:
+        k, ms, work = ctx.profile_read(cls)
+        if k and ms > 0 and (best is None or ms > best[2]):
+            best = (cls, k, ms, work)
+    if best is None:
+        return None
+    cls, k, ms, work = best
+    tf = work / (ms * 1e-3) / 1e12
+    return {"kernel": names[cls], "bound": "mfma", "achieved": tf, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": tf / PEAK_FP64_MFMA_TFLOPS, "traffic": None, "launches": k, "avg_launch_us": ms / k * 1e3,
+            "flops_per_launch_avg": work / k, "class_time_ms": ms}
 
 
 def run_secondary(args):
-    """Secondary workloads (not the headline metric): C3 batched LML+gradient sharded over ranks, C4 EP sweeps."""
+    """Secondary workloads (not the headline metric): C3 batched LML+gradient sharded over ranks with one all_gather of the
+    results, C4 EP sweeps (replicas only), C5 one 10^6-point posterior request split over the ranks."""
     import torch
     from gp_algos_amd import dist as gdist
     rank, local_rank, world = gdist.env_rank_world()
@@ -58,12 +112,18 @@ def run_secondary(args):
     if os.environ.get("GPCORE_BENCH_DEVICE") is not None:
         local_rank = int(os.environ["GPCORE_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
-    gdist.init(os.environ.get("GPCORE_BENCH_BACKEND", "nccl"), torch.device("cuda", local_rank))
+    backend = os.environ.get("GPCORE_BENCH_BACKEND", "nccl")
+    gdist.init(backend, torch.device("cuda", local_rank))
+    coll_dev = "cuda" if backend == "nccl" else "cpu"
     import __graft_entry__ as entry
     entry.build()
     from gp_algos_amd import _lib as L, synth
     from gp_algos_amd.core import Context, EpClassifierState
     ctx = Context(local_rank)
+    names = {L.GP_PROF_GEMM: "gemm_nt_f64_kernel<0,*> (general product: T = L^-T updates / rank-128 EP updates / posterior steps)",
+             L.GP_PROF_SYRK: "gemm_nt_f64_kernel<1,*> (lower-trapezoid product: Cholesky K=512 trailing update, T T^T, Sigma = K - Vt Vt^T)",
+             L.GP_PROF_PANEL_UPD: "gemm_nt_f64_kernel<1,1> (K = 128 in-panel update)"}
+    prof_mask = (1 << L.GP_PROF_GEMM) | (1 << L.GP_PROF_SYRK) | (1 << L.GP_PROF_PANEL_UPD)
 
     def fence():
         ctx.sync()
@@ -73,63 +133,108 @@ def run_secondary(args):
 
     if args.workload == "c3":
         n = args.n if args.n != 8192 else 4096
+        P = args.d + 2
         p = synth.config_c3(n, args.d)
         B = p["thetas"].shape[0]
         lo, hi = gdist.shard_range(B, rank, world)
-        mine = p["thetas"][lo:hi]
+        state = {}
+
+        def evaluate(th):                                    # this rank's settings on this rank's GPU
+            lml_, grad_, info_ = ctx.lml_grad_batched(p["X"], p["y"], th)
+            state["info"] = info_
+            return lml_, grad_
+
+        def step():                                          # settings sharded b -> rank b // ceil(B / world), results by ONE all_gather
+            return gdist.lml_grad_sharded(evaluate, p["thetas"], device=coll_dev)
+
         for _ in range(args.warmup):
-            ctx.lml_grad_batched(p["X"], p["y"], mine)      # same shapes as the timed steps: workspaces are allocated here
+            step()                                           # same shapes as the timed steps: workspaces are allocated here
         fence()
-        t0 = time.perf_counter()
+        ctx.profile(prof_mask)
+        t_rank = time.perf_counter()
         for _ in range(args.steps):
-            lml, grad, info = ctx.lml_grad_batched(p["X"], p["y"], mine)
+            lml, grad = step()
         fence()
-        dt = gdist.max_over_ranks(time.perf_counter() - t0, device="cuda")
+        t_rank = time.perf_counter() - t_rank
+        ctx.profile(0)
+        dt = gdist.max_over_ranks(t_rank, device=coll_dev)
+        times = gdist.all_gather_rows(np.array([[t_rank]]), world, device=coll_dev) if world > 1 else np.array([[t_rank]])
+        roof = _roofline_from_profile(ctx, L, (L.GP_PROF_GEMM, L.GP_PROF_SYRK, L.GP_PROF_PANEL_UPD), names)
+        # spot check outside the timed region: one setting alone (count = 1 forms of every step) against its lockstep result
+        b0 = lo if hi > lo else 0
+        one, gone, _ = ctx.lml_grad_batched(p["X"], p["y"], p["thetas"][b0:b0 + 1])
+        chk = float(max(abs(one[0] - lml[b0]) / abs(one[0]), np.max(np.abs(gone[0] - grad[b0])) / np.max(np.abs(gone[0]))))
         if rank == 0:
-            flops = (n ** 3) * (1 / 3 + 1 / 2 + 1 / 3) + 2.0 * (args.d + 2) * n * n
-            print(json.dumps({"metric": "LML+gradient settings/sec at n=%d fp64, P=%d" % (n, args.d + 2), "value": B * args.steps / dt,
+            # n^3/3 (potrf) + 2 n^3/3 (K^-1 from L) + 2 n^2 (alpha) + P 2 n^2 (fused traces) per setting
+            flops = float(n) ** 3 + (2.0 + 2.0 * P) * n * n
+            tf = flops * B * args.steps / dt / 1e12
+            print(json.dumps({"metric": "LML+gradient settings/sec at n=%d fp64, P=%d" % (n, P), "value": B * args.steps / dt,
                               "unit": "settings/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                               "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                               "dtype": "f64", "data": "synthetic",
-                              "config": {"workload": "C3: log-marginal-likelihood + gradient over %d hyper-parameter settings, n=%d d=%d, "
-                                                     "settings sharded %d per GPU" % (B, n, args.d, hi - lo), "B": B, "n": n},
-                              "approx_tflops_per_gpu": flops * (hi - lo) * args.steps / dt / 1e12,
-                              "lml_first": float(lml[0]), "all_pd": bool(np.all(info == 0))}), flush=True)
+                              "config": {"workload": "C3: log-marginal-likelihood + gradient over %d hyper-parameter settings, n=%d d=%d, settings "
+                                                     "sharded %d per GPU (b -> rank b // %d), every rank holds X and y, results assembled on "
+                                                     "every rank by one all_gather of (B/G) x (1+P) doubles per step"
+                                                     % (B, n, args.d, hi - lo, -(-B // world)), "B": B, "n": n,
+                                         "timed_region": "per step: upload of X, y (%d KB) + all settings of this rank + the all_gather" % ((n * args.d + n) * 8 // 1024)},
+                              "algorithmic_tflops_total": tf, "algorithmic_tflops_per_gpu": tf / world,
+                              "frac_of_fp64_mfma_peak_per_gpu": tf / world / PEAK_FP64_MFMA_TFLOPS,
+                              "roofline": roof, "per_rank_seconds": [float(t) for t in times[:, 0]],
+                              "lml_first": float(lml[0]), "lml_last": float(lml[-1]), "all_finite": bool(np.all(np.isfinite(lml)) and np.all(np.isfinite(grad))),
+                              "lockstep_vs_single_setting_max_rel": chk}), flush=True)
     elif args.workload == "c5":
         import ctypes as C
         n = args.n if args.n != 8192 else 32768
-        m = args.m if args.m != 65536 else 131072          # 1M test points / 8 GPUs, rounded to the batch size
+        m_total = args.m if args.m != 65536 else 1000000     # ONE request of 10^6 test points, split contiguously over the ranks
         p = synth.config_c5(n, args.d, 0)
-        i = (np.arange(m, dtype=np.uint64) + np.uint64(rank * m))[:, None]
+        lo, hi = gdist.shard_range(m_total, rank, world)
+        m = hi - lo
+        i = (np.arange(m, dtype=np.uint64) + np.uint64(lo))[:, None]
         k = np.arange(args.d, dtype=np.uint64)[None, :]
         Xs = np.asfortranarray(-2.0 + 4.0 * synth.u(43, i * np.uint64(args.d) + k))
         lib = ctx._lib
         dX, dy, dXs = ctx.upload(p["X"]), ctx.upload(p["y"]), ctx.upload(Xs)
-        dmean, dvar = ctx.dev_alloc(8 * m), ctx.dev_alloc(8 * m)
+        dmean, dvar = ctx.dev_alloc(8 * max(m, 1)), ctx.dev_alloc(8 * max(m, 1))
         theta = L.f64(p["theta"])
         h, info = C.c_void_p(), C.c_int()
         t0 = time.perf_counter()
         ctx.check(lib.gp_fit_rbf_dev(ctx.h, dX, n, args.d, n, dy, L.dptr(theta), float("nan"), C.byref(h), C.byref(info)), info.value)
         ctx.sync()
         t_fit = time.perf_counter() - t0
+
+        def step():   # this rank's slice of the request, then mean/variance assembled on every rank (2 m/G doubles per rank)
+            ctx.check(lib.gp_predict_dev(h, dXs, m, m, dmean, dvar))
+            local = np.stack([ctx.download(dmean, (m,)), ctx.download(dvar, (m,))], axis=1)
+            return gdist.all_gather_rows(local, m_total, device=coll_dev)
+
         for _ in range(max(args.warmup, 1)):
-            ctx.check(lib.gp_predict_dev(h, dXs, m, m, dmean, dvar))
+            step()
         fence()
-        t0 = time.perf_counter()
+        ctx.profile(prof_mask)
+        t_rank = time.perf_counter()
         for _ in range(args.steps):
-            ctx.check(lib.gp_predict_dev(h, dXs, m, m, dmean, dvar))
+            full = step()
         fence()
-        dt = gdist.max_over_ranks(time.perf_counter() - t0, device="cuda")
+        t_rank = time.perf_counter() - t_rank
+        ctx.profile(0)
+        dt = gdist.max_over_ranks(t_rank, device=coll_dev)
+        times = gdist.all_gather_rows(np.array([[t_rank]]), world, device=coll_dev) if world > 1 else np.array([[t_rank]])
+        roof = _roofline_from_profile(ctx, L, (L.GP_PROF_GEMM, L.GP_PROF_SYRK), names)
         if rank == 0:
-            var = ctx.download(dvar, (m,))
-            print(json.dumps({"metric": "posterior variances/sec at n=%d fp64 (L resident)" % n, "value": world * m * args.steps / dt,
+            var = full[:, 1]
+            print(json.dumps({"metric": "posterior variances/sec at n=%d fp64 (L resident)" % n, "value": m_total * args.steps / dt,
                               "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 1),
-                              "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                              "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                               "dtype": "f64", "data": "synthetic",
-                              "config": {"workload": "C5: n=%d d=%d fit once per GPU (first fit incl. allocation %.0f ms), %d test points per GPU "
-                                                     "per step in batches of up to 131072 rows (Vt <= 32 GiB)" % (n, args.d, t_fit * 1e3, m), "n": n, "m_per_gpu": m},
-                              "tflops_n2m": float(n) * n * m * args.steps / dt / 1e12 * world,
-                              "var_range": [float(var.min()), float(var.max())]}), flush=True)
+                              "config": {"workload": "C5: n=%d d=%d fit once per GPU (first fit incl. allocation %.0f ms), ONE request of %d test "
+                                                     "points split contiguously over the ranks (%d per GPU, batches of up to 131072 rows, Vt <= 32 GiB), "
+                                                     "mean and variance gathered on every rank" % (n, args.d, t_fit * 1e3, m_total, m),
+                                         "n": n, "m_total": m_total, "m_per_gpu": m,
+                                         "timed_region": "per step: predict of this rank's slice (X* resident) + D2H of 2 m/G doubles + all_gather"},
+                              "tflops_n2m_total": float(n) * n * m_total * args.steps / dt / 1e12,
+                              "tflops_n2m_per_gpu": float(n) * n * m_total * args.steps / dt / 1e12 / world,
+                              "roofline": roof, "per_rank_seconds": [float(t) for t in times[:, 0]],
+                              "var_range": [float(var.min()), float(var.max())], "gathered_rows": int(full.shape[0])}), flush=True)
         lib.gp_model_destroy(h)
     else:
         n = args.n if args.n != 8192 else 4096
@@ -139,18 +244,25 @@ def run_secondary(args):
         ep = EpClassifierState(ctx, K, p["y"])
         ep.sweep(1)
         fence()
+        ctx.profile(prof_mask)
         t0 = time.perf_counter()
         for _ in range(args.steps):
             tau, nu = ep.sweep(sweeps)
         fence()
-        dt = gdist.max_over_ranks(time.perf_counter() - t0, device="cuda")
+        dt = gdist.max_over_ranks(time.perf_counter() - t0, device=coll_dev)
+        ctx.profile(0)
+        roof = _roofline_from_profile(ctx, L, (L.GP_PROF_GEMM, L.GP_PROF_SYRK, L.GP_PROF_PANEL_UPD), names)
         if rank == 0:
+            tf = (13.0 / 3.0) * float(n) ** 3 * sweeps * args.steps / dt / 1e12    # 4 1/3 n^3 per sweep
             print(json.dumps({"metric": "EP sweeps/sec at n=%d fp64" % n, "value": world * sweeps * args.steps / dt, "unit": "sweeps/s",
                               "n_gpus": world, "steps": args.steps, "warmup": 1, "ms_per_step": dt / args.steps * 1e3,
                               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                               "config": {"workload": "C4: GP binary classification via EP, n=%d, %d sweeps per step (replicas only: one EP run "
                                                      "does not shard)" % (n, sweeps), "n": n, "sweeps": sweeps},
-                              "algorithmic_tflops": (13.0 / 3.0) * n ** 3 * sweeps * args.steps / dt / 1e12,
+                              "algorithmic_tflops": tf, "frac_of_fp64_mfma_peak": tf / PEAK_FP64_MFMA_TFLOPS,
+                              "executed_flops_note": "the sweep executes 2 2/3 n^3 (trailing-only rank-128 updates n^3/3, Cholesky n^3/3, "
+                                                     "V n^3, Sigma n^3), the 4 1/3 n^3 of SURVEY 8(d) counts full-square rank-1 updates",
+                              "roofline": roof,
                               "ep_lml_strict": ep.lml(True), "ep_lml_corrected": ep.lml(False),
                               "tau_range": [float(tau.min()), float(tau.max())]}), flush=True)
         ep.close()
@@ -167,6 +279,12 @@ def cpu_opt_baseline(p, sample_pts=4096):
     cho_solve, solve_triangular on a bounded sample of the test points.  This is the figure the north-star's
     ">= 10x the CPU wall-clock for full fit+predict" is judged against; the 1-core oracle above is the parity checker."""
     import scipy.linalg as sla
+    cores = host_cores()
+    try:
+        from threadpoolctl import threadpool_limits
+        limiter = threadpool_limits(limits=cores)
+    except Exception:
+        limiter = None
     X, y, theta = p["X"], p["y"], p["theta"]
     n = X.shape[0]
     sf2, sn2 = theta[0] ** 2, theta[-1] ** 2
@@ -192,7 +310,10 @@ def cpu_opt_baseline(p, sample_pts=4096):
     V = sla.solve_triangular(c[0], Ks.T, lower=True, check_finite=False, overwrite_b=True)
     var = (sf2 + sn2) - np.einsum("ij,ij->j", V, V)
     t_pred = time.perf_counter() - t0
-    return dict(kind="numpy/scipy LAPACK, all host cores", cores=os.cpu_count(), fit_s=t_fit, predict_points_per_s=k / t_pred,
+    if limiter is not None:
+        limiter.restore_original_limits()
+    return dict(kind="numpy/scipy LAPACK, BLAS threads = the cores this process may use", cores=cores, visible_cpus=os.cpu_count(),
+                fit_s=t_fit, predict_points_per_s=k / t_pred,
                 sample="fit at full n=%d; predict on %d of the test points" % (n, k)), mean, var, k
 
 
@@ -319,7 +440,10 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "C2: GP regression, ARD-RBF, n=%d d=%d fp64, Gram + Cholesky + posterior mean/variance at m=%d "
                                    "test points per GPU" % (n, d, m), "n": n, "d": d, "m_per_gpu": m,
-                       "parallelism": "test points sharded %d-way, model refit per rank, no data-path collective" % world},
+                       "parallelism": "test points sharded %d-way, model refit per rank, no data-path collective" % world,
+                       "timed_region": "X, y, X* resident in HBM before the timed steps; per step: Gram + Cholesky + alpha/LML refit, then mean "
+                                       "and variance of all m points, results left in HBM (H2D of X* = m*d*8 B and D2H of 2m doubles are outside "
+                                       "the timed region: 5 MB per step, DESIGN.md section 5)"},
             "roofline": {"kernel": DOMINANT_KERNEL + " (posterior step Vt_i = Vt[:, :128(i+1)] Lw_i^T: update and panel solve of block "
                                    "column i in one product on 256x128 tiles, one 8-wave workgroup (64x64 per wave) per CU, row reductions in the "
                                    "epilogue; v_mfma_f64_16x16x4_f64)",
@@ -343,7 +467,7 @@ def main():
         ctx.check(lib.gp_model_get(h, L.GP_GET_L, L.dptr(Lh), n))
         ah = np.zeros(n)
         ctx.check(lib.gp_model_get(h, L.GP_GET_ALPHA, L.dptr(ah), n))
-        base, cmean, cvar, kk = cpu_baseline(p, Lh, ah, 256)
+        base, cmean, cvar, kk = cpu_baseline(p, Lh, ah, m)
         gmean = ctx.download(dmean, (m,))[:kk]
         gvar = ctx.download(dvar, (m,))[:kk]
         base["max_abs_dmean_vs_gpu"] = float(np.max(np.abs(gmean - cmean)))

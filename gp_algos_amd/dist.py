@@ -85,3 +85,21 @@ def lml_grad_sharded(evaluate, thetas, device="cpu"):
         local = np.zeros((0, 1 + thetas.shape[1]))
     full = all_gather_rows(local, B, device=device)
     return full[:, 0].copy(), full[:, 1:].copy()
+
+
+def predict_sharded(predict, Xs, device="cpu"):
+    """ONE posterior request of m test points split over the ranks: rank r takes the contiguous rows
+    shard_range(m, r, world) of Xs, `predict(Xs_slice) -> (mean, var)` runs on its GPU (RegressionModel.predict /
+    gp_predict_dev against the factor that rank holds), and one all_gather of 2 m/G doubles per rank assembles
+    (mean[m], var[m]) on every rank.  No other collective: test points are independent units."""
+    rank, _, world = env_rank_world()
+    Xs = np.asarray(Xs)
+    m = Xs.shape[0]
+    lo, hi = shard_range(m, rank, world)
+    if hi > lo:
+        mean, var = predict(Xs[lo:hi])
+        local = np.stack([np.asarray(mean, dtype=np.float64), np.asarray(var, dtype=np.float64)], axis=1)
+    else:
+        local = np.zeros((0, 2))
+    full = all_gather_rows(local, m, device=device)
+    return full[:, 0].copy(), full[:, 1].copy()

@@ -45,8 +45,19 @@ def _worker(rank, world, port, out):
 
     lml, grad = dist.lml_grad_sharded(evaluate, thetas)
     tmax = dist.max_over_ranks(10.0 + rank)
+    # one posterior request of 7 test points split 4 + 3 (config C5's sharding): every rank fits the same model
+    Lf, alpha = orc.fit(p["X"], p["y"], thetas[0])
+    Xs = synth.regression(24, 2, 7, 5, 6, 9, thetas[0])["Xs"]
+    pcalls = []
+
+    def predict(xs):
+        pcalls.append(len(xs))
+        mean, var, _, _ = orc.predict(p["X"], thetas[0], Lf, alpha, np.asfortranarray(xs))
+        return mean, var
+
+    pmean, pvar = dist.predict_sharded(predict, Xs)
     dist.barrier()
-    out.put((rank, calls, lml, grad, tmax))
+    out.put((rank, calls, lml, grad, tmax, pcalls, pmean, pvar))
     import torch.distributed as td
     td.destroy_process_group()
 
@@ -73,7 +84,13 @@ def test_lml_grad_sharded_two_ranks_gloo():
     thetas = np.stack([synth.ard_theta(2, sf, s, 0.2) for sf in (0.8, 1.3) for s in (0.7, 1.0, 1.6)][:5])
     ref = [orc.lml_grad(p["X"], p["y"], t) for t in thetas]
     assert res[0][1] == [3] and res[1][1] == [2]            # each rank evaluated only its own settings
-    for rank, calls, lml, grad, tmax in res:
+    Lf, alpha = orc.fit(p["X"], p["y"], thetas[0])
+    Xs = synth.regression(24, 2, 7, 5, 6, 9, thetas[0])["Xs"]
+    rmean, rvar, _, _ = orc.predict(p["X"], thetas[0], Lf, alpha, Xs)
+    assert res[0][5] == [4] and res[1][5] == [3]            # the 7 test points were split 4 + 3, each rank predicted only its slice
+    for rank, calls, lml, grad, tmax, pcalls, pmean, pvar in res:
         assert tmax == 11.0                                   # max over ranks
         np.testing.assert_array_equal(lml, [r[0] for r in ref])    # assembled in setting order on every rank
         np.testing.assert_array_equal(grad, np.stack([r[1] for r in ref]))
+        np.testing.assert_array_equal(pmean, rmean)          # assembled in test-point order on every rank
+        np.testing.assert_array_equal(pvar, rvar)
