@@ -164,6 +164,25 @@ def run_secondary(args):
         b0 = lo if hi > lo else 0
         one, gone, _ = ctx.lml_grad_batched(p["X"], p["y"], p["thetas"][b0:b0 + 1])
         chk = float(max(abs(one[0] - lml[b0]) / abs(one[0]), np.max(np.abs(gone[0] - grad[b0])) / np.max(np.abs(gone[0]))))
+        # The same sharded evaluation through the C-ABI's own RCCL entry point (gp_dist_lml_grad_batched: what a Scala host
+        # calls), outside the timed region, against the torch.distributed result: only on real multi-GPU runs
+        cabi = None
+        if world > 1 and backend == "nccl":
+            try:
+                import torch.distributed as tdist
+                from gp_algos_amd.core import DistGroup
+
+                def exchange(ident):
+                    obj = [ident]
+                    tdist.broadcast_object_list(obj, src=0, device=torch.device("cuda", local_rank))
+                    return obj[0]
+
+                grp = DistGroup(ctx, rank, world, exchange)
+                l2, g2, _ = grp.lml_grad_batched(p["X"], p["y"], p["thetas"])
+                cabi = bool(np.array_equal(l2, lml) and np.array_equal(g2, grad))
+                grp.close()
+            except Exception as e:   # reported, never fatal for the benchmark line
+                cabi = "failed: %s" % e
         if rank == 0:
             # n^3/3 (potrf) + 2 n^3/3 (K^-1 from L) + 2 n^2 (alpha) + P 2 n^2 (fused traces) per setting
             flops = float(n) ** 3 + (2.0 + 2.0 * P) * n * n
@@ -181,7 +200,7 @@ def run_secondary(args):
                               "frac_of_fp64_mfma_peak_per_gpu": tf / world / PEAK_FP64_MFMA_TFLOPS,
                               "roofline": roof, "per_rank_seconds": [float(t) for t in times[:, 0]],
                               "lml_first": float(lml[0]), "lml_last": float(lml[-1]), "all_finite": bool(np.all(np.isfinite(lml)) and np.all(np.isfinite(grad))),
-                              "lockstep_vs_single_setting_max_rel": chk}), flush=True)
+                              "lockstep_vs_single_setting_max_rel": chk, "c_abi_rccl_allgather_matches": cabi}), flush=True)
     elif args.workload == "c5":
         import ctypes as C
         n = args.n if args.n != 8192 else 32768
@@ -368,7 +387,16 @@ def main():
     lib = ctx._lib
     probe = ctx.probe_mfma_f64()
     dX, dy, dXs = ctx.upload(p["X"]), ctx.upload(p["y"]), ctx.upload(p["Xs"])
-    dmean, dvar = ctx.dev_alloc(8 * m), ctx.dev_alloc(8 * m)
+    gathered = None
+    if world > 1 and backend == "nccl":
+        # N > 1: the posterior of the N*m test points is ASSEMBLED on every rank -- this rank's (mean | variance) slice lives in
+        # a torch tensor the library writes through its raw pointer, and one all_gather per step (RCCL over xGMI, 2 m doubles
+        # = 1 MB per rank) follows the predict inside the timed region
+        dout_t = torch.empty(2 * m, dtype=torch.float64, device="cuda")
+        gathered = torch.empty(world * 2 * m, dtype=torch.float64, device="cuda")
+        dmean, dvar = C.c_void_p(dout_t.data_ptr()), C.c_void_p(dout_t.data_ptr() + 8 * m)
+    else:
+        dmean, dvar = ctx.dev_alloc(8 * m), ctx.dev_alloc(8 * m)
     theta = L.f64(p["theta"])
     nan = float("nan")
     h, info = C.c_void_p(), C.c_int()
@@ -377,6 +405,9 @@ def main():
     def step():
         ctx.check(lib.gp_model_refit_dev(h, L.dptr(theta), nan))
         ctx.check(lib.gp_predict_dev(h, dXs, m, m, dmean, dvar))
+        if gathered is not None:
+            ctx.sync()                                        # the library runs on its own stream; torch's collective on torch's
+            dist.all_gather_into_tensor(gathered, dout_t)
 
     def fence():
         ctx.sync()
@@ -440,7 +471,10 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "C2: GP regression, ARD-RBF, n=%d d=%d fp64, Gram + Cholesky + posterior mean/variance at m=%d "
                                    "test points per GPU" % (n, d, m), "n": n, "d": d, "m_per_gpu": m,
-                       "parallelism": "test points sharded %d-way, model refit per rank, no data-path collective" % world,
+                       "parallelism": ("test points sharded %d-way (m per GPU), model refit per rank; the posterior of all %d points is "
+                                       "assembled on every rank by one all_gather of 2 m doubles per rank per step (RCCL)" % (world, world * m))
+                       if gathered is not None else "single GPU" if world == 1 else
+                       "test points sharded %d-way, model refit per rank, results left on the rank (rehearsal backend)" % world,
                        "timed_region": "X, y, X* resident in HBM before the timed steps; per step: Gram + Cholesky + alpha/LML refit, then mean "
                                        "and variance of all m points, results left in HBM (H2D of X* = m*d*8 B and D2H of 2m doubles are outside "
                                        "the timed region: 5 MB per step, DESIGN.md section 5)"},

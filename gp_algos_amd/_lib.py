@@ -8,7 +8,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgpcore.so")
 
-GP_OK, GP_EINVAL, GP_ENOTPD, GP_ENOMEM, GP_EHIP, GP_ERANGE = range(6)
+GP_OK, GP_EINVAL, GP_ENOTPD, GP_ENOMEM, GP_EHIP, GP_ERANGE, GP_ERCCL = range(7)
+GP_DIST_ID_BYTES = 128
 GP_LOWER, GP_FULL = 0, 1
 GP_GET_L, GP_GET_ALPHA, GP_GET_LML = 0, 1, 2
 GP_PROF_OFF, GP_PROF_GEMM, GP_PROF_SYRK, GP_PROF_GRAM, GP_PROF_TRSM, GP_PROF_POTRF_DIAG, GP_PROF_PANEL_UPD = range(7)
@@ -66,6 +67,12 @@ SIGNATURES = {
     "gp_ep_predict": (_i, [_vp, _dp, _i, _i, _dp, _dp]),
     "gp_ep_lml_rbf_batched": (_i, [_vp, _dp, _i, _i, _i, C.POINTER(C.c_int32), _dp, _i, _d, _i, _i, _dp, _ip, _ip]),
     "gp_ep_destroy": (None, [_vp]),
+    "gp_dist_unique_id": (_i, [_vp, C.c_char_p]),
+    "gp_dist_init": (_i, [_vp, C.c_char_p, _i, _i, C.POINTER(_vp)]),
+    "gp_dist_destroy": (None, [_vp]),
+    "gp_dist_shard": (_i, [_vp, _i, _ip, _ip]),
+    "gp_dist_lml_grad_batched": (_i, [_vp, _dp, _i, _i, _i, _dp, _dp, _i, _i, _d, _dp, _dp, _ip]),
+    "gp_dist_predict": (_i, [_vp, _vp, _dp, _i, _i, _dp, _dp]),
 }
 
 _lib = None

@@ -308,6 +308,61 @@ class RegressionModel:
         return mean, var, cov
 
 
+class DistGroup:
+    """gp_dist_*: this rank's RCCL communicator on `ctx`'s device (one process per GPU).  `exchange(id_bytes_or_None) -> id_bytes`
+    ships rank 0's 128-byte id to every rank (torch.distributed broadcast, a file, a socket ...)."""
+
+    def __init__(self, ctx, rank, world, exchange=None):
+        self.ctx, self.rank, self.world = ctx, int(rank), int(world)
+        lib = ctx._lib
+        buf = C.create_string_buffer(L.GP_DIST_ID_BYTES)
+        if self.rank == 0:
+            ctx.check(lib.gp_dist_unique_id(ctx.h, buf))
+        ident = bytes(buf.raw)
+        if exchange is not None:
+            ident = exchange(ident if self.rank == 0 else None)
+        if len(ident) != L.GP_DIST_ID_BYTES:
+            raise ValueError("the RCCL id must be %d bytes" % L.GP_DIST_ID_BYTES)
+        h = C.c_void_p()
+        ctx.check(lib.gp_dist_init(ctx.h, C.create_string_buffer(ident, L.GP_DIST_ID_BYTES), self.rank, self.world, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None) and getattr(self.ctx, "h", None):
+            self.ctx._lib.gp_dist_destroy(self.h)
+        self.h = None
+
+    __del__ = close
+
+    def shard(self, total):
+        lo, hi = C.c_int(), C.c_int()
+        self.ctx.check(self.ctx._lib.gp_dist_shard(self.h, int(total), C.byref(lo), C.byref(hi)))
+        return lo.value, hi.value
+
+    def lml_grad_batched(self, X, y, thetas, nparams=None, sigma_noise=None):
+        X, y = L.f64(X), L.f64(y)
+        n, d = X.shape
+        thetas = np.ascontiguousarray(np.atleast_2d(thetas), dtype=np.float64)
+        B, P = thetas.shape
+        if P != d + 2 or y.size != n:
+            raise ValueError("dimension mismatch")
+        nparams = P if nparams is None else int(nparams)
+        lml, grad, info = np.zeros(B), np.zeros((B, max(nparams, 1))), np.zeros(B, dtype=np.int32)
+        sn = float("nan") if sigma_noise is None else float(sigma_noise)
+        self.ctx.check(self.ctx._lib.gp_dist_lml_grad_batched(self.h, L.dptr(X), n, d, n, L.dptr(y), L.dptr(thetas), B, nparams, sn,
+                                                              L.dptr(lml), L.dptr(grad), info.ctypes.data_as(C.POINTER(C.c_int))))
+        return lml, grad[:, :nparams], info
+
+    def predict(self, model, Xs):
+        Xs = L.f64(Xs)
+        m = Xs.shape[0]
+        if Xs.shape[1] != model.d:
+            raise ValueError("test data dimension mismatch")
+        mean, var = np.zeros(m), np.zeros(m)
+        self.ctx.check(self.ctx._lib.gp_dist_predict(self.h, model.h, L.dptr(Xs), m, max(m, 1), L.dptr(mean), L.dptr(var)))
+        return mean, var
+
+
 class EpClassifierState:
     """EpParameterEstimator state on the GPU: K, Sigma, L and the site parameters."""
 

@@ -35,12 +35,14 @@ typedef enum gp_status {
     GP_ENOTPD = 2, /* matrix not positive definite; *info = 1-based failing pivot (Breeze throws)  */
     GP_ENOMEM = 3, /* host or device allocation failed                                            */
     GP_EHIP = 4,   /* HIP runtime error (message in gp_last_error)                                */
-    GP_ERANGE = 5  /* 1-based hyper-parameter position out of range (Scala: MatchError)           */
+    GP_ERANGE = 5, /* 1-based hyper-parameter position out of range (Scala: MatchError)           */
+    GP_ERCCL = 6   /* RCCL missing or a collective failed (message in gp_last_error)               */
 } gp_status;
 
 typedef struct gp_ctx gp_ctx;     /* device + stream + workspaces                                  */
 typedef struct gp_model gp_model; /* fitted regression model: X, L, alpha resident in HBM          */
 typedef struct gp_ep gp_ep;       /* EP classification state: K, Sigma, L, site parameters in HBM  */
+typedef struct gp_dist gp_dist;   /* RCCL communicator of one rank (one process per GPU)           */
 
 /* ---- library / context ------------------------------------------------------------------- */
 const char *gp_version(void);
@@ -192,6 +194,28 @@ gp_status gp_ep_predict(gp_ep *ep, const double *Ks, int m, int ldks, const doub
  * failing pivot of I + S^1/2 K S^1/2 with lml = NaN).  The reference's mis-keyed result map is not replicated. */
 gp_status gp_ep_lml_rbf_batched(gp_ctx *ctx, const double *X, int n, int d, int ldx, const int32_t *y, const double *thetas, int B, double stop_eps, int max_sweeps, int strict, double *lml, int *sweeps, int *info);
 void gp_ep_destroy(gp_ep *ep);
+
+/* ---- multi-GPU: one process per GPU, RCCL over xGMI ------------------------------------------- */
+/* The reference has no distributed code; these drive its two embarrassingly parallel loops: the settings that
+ * GpPredictor.obtainOptimalHyperParams (gp/regression/GpPredictor.scala:126-142) / MeshHyperParamsLogLikelihoodEvaluator
+ * (gp/classification/MeshHyperParamsLogLikelihoodEvaluator.scala:26-40) visit one by one, and the rows of testData in
+ * GpPredictor.predict (:24-43).  Units are sharded contiguously, unit u -> rank u / ceil(U / world); every rank passes the SAME
+ * arguments and receives the complete result; the only collective is ONE all-gather of the per-rank results per call.  The
+ * Cholesky itself stays single-GPU.  RCCL is loaded at run time; without it these return GP_ERCCL.
+ * Rendezvous: rank 0 obtains an id and hands its GP_DIST_ID_BYTES bytes to the other ranks over whatever channel the host
+ * program has (a file, a socket, torch.distributed); then every rank calls gp_dist_init on the context of ITS device. */
+#define GP_DIST_ID_BYTES 128
+gp_status gp_dist_unique_id(gp_ctx *ctx, unsigned char *id /* [GP_DIST_ID_BYTES] */);
+gp_status gp_dist_init(gp_ctx *ctx, const unsigned char *id, int rank, int world, gp_dist **out);
+void gp_dist_destroy(gp_dist *dist);
+/* [lo, hi) of `total` units owned by this rank */
+gp_status gp_dist_shard(const gp_dist *dist, int total, int *lo, int *hi);
+/* gp_lml_grad_rbf_batched over B settings sharded B/world per GPU (BASELINE config C3); lml[B], grad[B x nparams], info[B]
+ * complete on every rank. */
+gp_status gp_dist_lml_grad_batched(gp_dist *dist, const double *X, int n, int d, int ldx, const double *y, const double *thetas, int B, int nparams, double sigma_noise, double *lml, double *grad, int *info);
+/* gp_predict (mean + diagonal variance) of ONE request of m test points sharded m/world per GPU (BASELINE config C5); `model`
+ * is this rank's own fitted model (every rank fits redundantly: cheaper than shipping L); mean[m], var[m] complete on every rank. */
+gp_status gp_dist_predict(gp_dist *dist, gp_model *model, const double *Xs, int m, int ldxs, double *mean, double *var);
 
 #ifdef __cplusplus
 }
