@@ -19,6 +19,7 @@ constexpr int GP_DMAX = 64;
 struct GramParams {
     double sf2, sn2, extra;
     double inv_ls2[GP_DMAX];
+    double inv_ls[GP_DMAX];    // 1 / l_k (the matrix-core form scales the features once)
     // derivative mode (GaussianRbfKernel.derAfterHyperParam, KernelRequisites.scala:76-86): 0 = the kernel itself,
     // 1 = d/d sf (2 sf e), 2 = d/d l_k (sf^2 e (x_k - y_k)^2 l_k^-3, k = dk), 3 = d/d sn (same ? 2 sn : 0)
     int dmode, dk;
@@ -104,6 +105,107 @@ __global__ __launch_bounds__(256) void gram_rbf_kernel(const double *__restrict_
     }
 }
 
+// The same Gram matrices with the X X^T term of the squared distance on the matrix cores (north star: "MFMA on the X.X^T term
+// of the squared-distance kernel"):  with z = (x - c) / l  (c = the first training point, a common shift that leaves every
+// difference unchanged and keeps the norms small),
+//     r^2_ij = |z_i|^2 + |z_j|^2 - 2 z_i . z_j,        K_ij = sf^2 exp(-r^2_ij / 2) (+ sn^2 on the diagonal, written exactly).
+// The per-pair form above spends 3 d + ~30 fp64 VALU instructions per entry (d = 8: ~55) and is VALU-bound at 3.7 TB/s of
+// stores; here the d-dependent part is 2 d / 4 MFMA k-steps in the matrix pipe, which runs beside the VALU, and what is left
+// per entry (norm adds, clamp, exp, scale) fits under the HBM store time.  Rounding: the error of r^2 is ABSOLUTE, a few ulp
+// of |z|^2, i.e. a RELATIVE error of the same size in K = exp(-r^2/2): ~1e-15 for the configurations here, inside the 1e-13
+// the parity tests state (GPCORE_GRAM_MFMA=0 selects the per-pair form, which follows the reference's own operation order).
+// One 256-thread workgroup per 64 x 64 tile: scaled features staged in LDS in chunks of 16 ([k][row], row stride 80 doubles
+// -> conflict-free fragment reads), wave w owns the tile's 16-column block w and its 4 row blocks.  MFMA operand roles put the
+// ROW index on lane & 15, so every store instruction writes 4 full 128-byte lines of column-major K.
+typedef double gram_d4 __attribute__((ext_vector_type(4)));
+constexpr int ZS = 80;      // LDS row stride (doubles): 640 B = 128 (mod 256)
+constexpr int ZC = 16;      // features per staged chunk
+
+template <bool SYM>
+__global__ __launch_bounds__(256) void gram_mfma_kernel(const double *__restrict__ Xr, int nr, int ldxr, const double *__restrict__ Xc,
+                                                        int nc, int ldxc, int d, GramParams prm, const double *__restrict__ center, int ldcen,
+                                                        double *__restrict__ K, int ldk, int full, int nbr) {
+    __shared__ __attribute__((aligned(16))) double zr[ZC * ZS], zc[ZC * ZS];
+    __shared__ double nrm[2][GT];
+    __shared__ double tile[SYM ? GT * (GT + 1) : 1];
+    int bi, bj;
+    if (SYM) tile_lower(blockIdx.x, bi, bj);
+    else { bi = blockIdx.x % nbr; bj = blockIdx.x / nbr; }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fk = lane >> 4;
+    const int i0 = bi * GT, j0 = bj * GT;
+    gram_d4 acc[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) acc[it] = (gram_d4){0.0, 0.0, 0.0, 0.0};
+    double nacc = 0.0;   // threads 0-63: |z|^2 of row i0 + tid; threads 64-127: of column j0 + tid - 64
+    // rows / columns past the end are clamped to the last point: their products are computed and never stored
+    const double *xr = Xr + min(i0 + lane, nr - 1), *xc = Xc + min(j0 + lane, nc - 1);
+    for (int kc = 0; kc < d; kc += ZC) {
+        if (kc) __syncthreads();
+        // stage the chunk: thread -> (point = lane, feature = wave + 4 q)
+#pragma unroll
+        for (int q = 0; q < ZC / 4; ++q) {
+            const int kk = wave + 4 * q, k = kc + kk;
+            double vr = 0.0, vc = 0.0;
+            if (k < d) {
+                const double cen = center[(size_t)k * ldcen], il = prm.inv_ls[k];
+                vr = (xr[(size_t)k * ldxr] - cen) * il;
+                vc = (xc[(size_t)k * ldxc] - cen) * il;
+            }
+            zr[kk * ZS + lane] = vr;
+            zc[kk * ZS + lane] = vc;
+        }
+        __syncthreads();
+        if (tid < 2 * GT) {
+            const double *z = (tid < GT) ? zr : zc;
+#pragma unroll
+            for (int kk = 0; kk < ZC; ++kk) nacc = fma(z[kk * ZS + lane], z[kk * ZS + lane], nacc);
+        }
+        const int ksteps = (min(d - kc, ZC) + 3) / 4;
+        for (int ks = 0; ks < ksteps; ++ks) {
+            const double a = zc[(4 * ks + fk) * ZS + 16 * wave + fr];       // column point j0 + 16 wave + fr, feature 4 ks + fk
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const double b = zr[(4 * ks + fk) * ZS + 16 * it + fr];     // row point i0 + 16 it + fr
+                acc[it] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[it], 0, 0, 0);   // reg r: (j = fk + 4 r, i = fr)
+            }
+        }
+    }
+    if (tid < 2 * GT) nrm[tid >> 6][lane] = nacc;
+    __syncthreads();
+    const bool diag_tile = SYM && (bi == bj);
+    // interior off-diagonal tiles (nearly all of them) store without per-element tests
+    const bool plain = !diag_tile && (i0 + GT <= nr) && (j0 + GT <= nc);
+    double *Kp = K + (i0 + fr) + (size_t)(j0 + 16 * wave + fk) * ldk;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int il = 16 * it + fr, gi = i0 + il;
+        const double ni = nrm[0][il];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int jl = 16 * wave + fk + 4 * r, gj = j0 + jl;
+            const double r2 = fmax(fma(-2.0, acc[it][r], ni + nrm[1][jl]), 0.0);
+            double v = prm.sf2 * exp(-0.5 * r2);
+            if (plain) {
+                Kp[16 * it + (size_t)(4 * r) * ldk] = v;
+            } else {
+                if (SYM && gi == gj) v = (prm.sf2 + prm.sn2) + prm.extra;      // exp(-0) == 1: sf*sf*1 + sn*sn (+ sigmaNoise), exact
+                if (gi < nr && gj < nc && !(diag_tile && !full && gi < gj)) Kp[16 * it + (size_t)(4 * r) * ldk] = v;
+            }
+            if (SYM) tile[il * (GT + 1) + jl] = v;
+        }
+    }
+    if (SYM && full && !diag_tile) {
+        __syncthreads();
+        const int ti = tid & 63, tq = tid >> 6;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int b = tq + 4 * q, a = ti;
+            const int r = j0 + a, c = i0 + b;
+            if (r < nc && c < nr) K[r + (size_t)c * ldk] = tile[b * (GT + 1) + a];
+        }
+    }
+}
+
 __global__ void pad_identity_kernel(double *A, int n, int np, int lda) {
     // zero rows [n,np) x cols [0,np) and rows [0,n) x cols [n,np); ones on the pad diagonal
     const int pad = np - n;
@@ -145,16 +247,33 @@ GramParams make_params(const double *theta, int d, double extra) {
     p.sn2 = theta[d + 1] * theta[d + 1];
     p.extra = extra;
     p.dmode = 0, p.dk = 0, p.dcoef = 0.0;
-    for (int k = 0; k < GP_DMAX; ++k) p.inv_ls2[k] = 0.0;
-    for (int k = 0; k < d; ++k) p.inv_ls2[k] = 1.0 / (theta[1 + k] * theta[1 + k]);
+    for (int k = 0; k < GP_DMAX; ++k) p.inv_ls2[k] = p.inv_ls[k] = 0.0;
+    for (int k = 0; k < d; ++k) {
+        p.inv_ls2[k] = 1.0 / (theta[1 + k] * theta[1 + k]);
+        p.inv_ls[k] = 1.0 / fabs(theta[1 + k]);
+    }
     return p;
 }
 
 }  // namespace
 
+// Which form builds the Gram matrices.  Measured on MI355X (tools/gram_perf.py, n = 8192, m = 65536): at d = 8 the per-pair form
+// wins (cross-Gram 1.21 vs 1.24 ms, lower Gram 84 vs 104 us: both are bound by VALU issue and by the load -> barrier -> store
+// life cycle of a tile, not by the store stream -- a store-only kernel with the same tile pattern reaches 5.4 TB/s, memset
+// 6.4 TB/s), at d = 32 the matrix-core form wins (1.95 vs 2.68 ms), so the default switches at d >= 16.
+// GPCORE_GRAM_MFMA=1 / 0 forces one form (read per call: the tests run both in one process).
+static bool gram_mfma(int d) {
+    const char *e = getenv("GPCORE_GRAM_MFMA");
+    return e ? atoi(e) != 0 : d >= 16;
+}
+
 void gpk_gram_sym(hipStream_t s, const double *X, int n, int d, int ldx, const double *theta, double *K, int ldk, int full, double extra_diag) {
     GramParams p = make_params(theta, d, extra_diag);
     int nb = (n + GT - 1) / GT;
+    if (gram_mfma(d)) {
+        hipLaunchKernelGGL(gram_mfma_kernel<true>, dim3(nb * (nb + 1) / 2), dim3(256), 0, s, X, n, ldx, X, n, ldx, d, p, X, ldx, K, ldk, full, nb);
+        return;
+    }
     hipLaunchKernelGGL(gram_rbf_kernel<true>, dim3(nb * (nb + 1) / 2), dim3(256), 0, s, X, n, ldx, X, n, ldx, d, p, K, ldk, full, nb);
 }
 
@@ -171,6 +290,10 @@ void gpk_dgram_sym(hipStream_t s, const double *X, int n, int d, int ldx, const 
 void gpk_gram_cross(hipStream_t s, const double *Xs, int m, int ldxs, const double *X, int n, int ldx, int d, const double *theta, double *Ks, int ldks) {
     GramParams p = make_params(theta, d, 0.0);
     int nbr = (m + GT - 1) / GT, nbc = (n + GT - 1) / GT;
+    if (gram_mfma(d)) {   // centre = first TRAINING point for both operands
+        hipLaunchKernelGGL(gram_mfma_kernel<false>, dim3(nbr * nbc), dim3(256), 0, s, Xs, m, ldxs, X, n, ldx, d, p, X, ldx, Ks, ldks, 1, nbr);
+        return;
+    }
     hipLaunchKernelGGL(gram_rbf_kernel<false>, dim3(nbr * nbc), dim3(256), 0, s, Xs, m, ldxs, X, n, ldx, d, p, Ks, ldks, 1, nbr);
 }
 

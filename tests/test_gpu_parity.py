@@ -50,6 +50,28 @@ def test_gram_sym_vs_oracle(ctx, n, d):
     assert np.max(np.abs(K - Ko) / np.abs(Ko)) <= TOL_GRAM
 
 
+@pytest.mark.parametrize("force", ["1", "0"])
+@pytest.mark.parametrize("n,d,m", [(70, 1, 33), (257, 8, 130), (200, 19, 77), (129, 64, 65)])
+def test_gram_forms_matrix_core_and_per_pair(ctx, monkeypatch, force, n, d, m):
+    """Both builders of the Gram matrices at every feature count: r^2 = |z_i|^2 + |z_j|^2 - 2 z_i.z_j with the dot products on
+    the matrix cores (default for d >= 16) and the reference's per-pair sum (default below).  Same tolerance, exact diagonal,
+    exact symmetry, odd sizes, feature counts that are not multiples of 4 or 16."""
+    monkeypatch.setenv("GPCORE_GRAM_MFMA", force)
+    p = _problem(n, d, m, seed=11 * n + d)
+    K = ctx.gram_rbf(p["X"], p["theta"])
+    Ko = orc.gram_sym(p["X"], p["theta"])
+    assert np.max(np.abs(K - Ko) / np.abs(Ko)) <= TOL_GRAM
+    assert np.array_equal(np.diag(K), np.diag(Ko)) and np.array_equal(K, K.T)
+    Ks = ctx.cross_gram_rbf(p["Xs"], p["X"], p["theta"])
+    Kso = orc.gram_cross(p["Xs"], p["X"], p["theta"])
+    assert np.max(np.abs(Ks - Kso) / np.abs(Kso)) <= TOL_GRAM
+    # inputs far from the origin: the common shift keeps the norms (and the absolute error of r^2) small
+    shift = 1.0e4 * np.ones(d)
+    Kf = ctx.gram_rbf(np.asfortranarray(p["X"] + shift), p["theta"])
+    Kfo = orc.gram_sym(np.asfortranarray(p["X"] + shift), p["theta"])
+    assert np.max(np.abs(Kf - Kfo) / np.abs(Kfo)) <= 2e-12        # x + 1e4 itself rounds differences to ~1e-12 relative
+
+
 def test_gram_lower_leaves_upper_untouched(ctx):
     p = _problem(130, 4, 0)
     out = np.full((130, 130), -7.0, order="F")
