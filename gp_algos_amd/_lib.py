@@ -14,6 +14,8 @@ GP_LOWER, GP_FULL = 0, 1
 GP_GET_L, GP_GET_ALPHA, GP_GET_LML = 0, 1, 2
 GP_PROF_OFF, GP_PROF_GEMM, GP_PROF_SYRK, GP_PROF_GRAM, GP_PROF_TRSM, GP_PROF_POTRF_DIAG, GP_PROF_PANEL_UPD = range(7)
 GP_EP_GET_L, GP_EP_GET_SIGMA, GP_EP_GET_MU, GP_EP_GET_CAV_TAU, GP_EP_GET_CAV_NU = range(5)
+GP_SMALL_GET_L, GP_SMALL_GET_LINV, GP_SMALL_GET_ALPHA = range(3)
+GP_SMALL_MAX_N = 2048
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
@@ -67,6 +69,15 @@ SIGNATURES = {
     "gp_ep_predict": (_i, [_vp, _dp, _i, _i, _dp, _dp]),
     "gp_ep_lml_rbf_batched": (_i, [_vp, _dp, _i, _i, _i, C.POINTER(C.c_int32), _dp, _i, _d, _i, _i, _dp, _ip, _ip]),
     "gp_ep_destroy": (None, [_vp]),
+    "gp_small_fit": (_i, [_vp, _dp, _i, _i, _i, _dp, _i, _i, _dp, _d, _i, C.POINTER(_vp), _ip]),
+    "gp_small_from_factors": (_i, [_vp, _dp, _i, _i, _i, _dp, _i, _dp, _i, _dp, _i, C.POINTER(_vp)]),
+    "gp_small_destroy": (None, [_vp]),
+    "gp_small_size": (_i, [_vp, _ip, _ip, _ip]),
+    "gp_small_get": (_i, [_vp, _i, _i, _dp, _i]),
+    "gp_small_posterior": (_i, [_vp, _dp, _i, _i, _dp, _dp]),
+    "gp_small_ucb": (_i, [_vp, _i, _dp, _i, _i, _d, _dp, _dp]),
+    "gp_small_append": (_i, [_vp, _dp, _dp, _ip]),
+    "gp_small_maximize_ucb": (_i, [_vp, _i, _dp, _i, _i, _d, _i, _i, _dp, _dp, _ip]),
     "gp_dist_unique_id": (_i, [_vp, C.c_char_p]),
     "gp_dist_init": (_i, [_vp, C.c_char_p, _i, _i, C.POINTER(_vp)]),
     "gp_dist_destroy": (None, [_vp]),

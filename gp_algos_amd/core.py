@@ -308,6 +308,87 @@ class RegressionModel:
         return mean, var, cov
 
 
+class SmallModelBatch:
+    """gp_small_*: G small GP models over ONE set of training inputs, resident with L^-1 (GP-UCB / GP-UKF workloads)."""
+
+    def __init__(self, ctx, X, thetas, Y=None, Ls=None, alphas=None, sigma_noise=None, capacity=0):
+        self.ctx = ctx
+        X = L.f64(X)
+        self.n0, self.d = X.shape
+        thetas = np.ascontiguousarray(np.atleast_2d(thetas), dtype=np.float64)
+        self.G = thetas.shape[0]
+        if thetas.shape[1] != self.d + 2:
+            raise ValueError("%d does not equal to %d" % (thetas.shape[1], self.d + 2))
+        h, info = C.c_void_p(), C.c_int()
+        n = self.n0
+        if Y is not None:
+            Y = L.f64(np.asarray(Y, dtype=np.float64).reshape(n, -1))
+            if Y.shape[1] != self.G:
+                raise ValueError("one target column per model")
+            sn = float("nan") if sigma_noise is None else float(sigma_noise)
+            st = ctx._lib.gp_small_fit(ctx.h, L.dptr(X), n, self.d, n, L.dptr(Y), n, self.G, L.dptr(thetas), sn, int(capacity), C.byref(h), C.byref(info))
+        else:
+            Ls = np.asfortranarray(np.concatenate([L.f64(a) for a in Ls], axis=1))       # n x (G n): model g at columns [g n, (g+1) n)
+            alphas = np.ascontiguousarray(np.stack([np.asarray(a, dtype=np.float64) for a in alphas]))
+            if Ls.shape != (n, self.G * n) or alphas.shape != (self.G, n):
+                raise ValueError("dimension mismatch")
+            st = ctx._lib.gp_small_from_factors(ctx.h, L.dptr(X), n, self.d, n, L.dptr(thetas), self.G, L.dptr(Ls), n, L.dptr(alphas), int(capacity), C.byref(h))
+        ctx.check(st, info.value)
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None) and getattr(self.ctx, "h", None):
+            self.ctx._lib.gp_small_destroy(self.h)
+        self.h = None
+
+    __del__ = close
+
+    @property
+    def n(self):
+        n = C.c_int()
+        self.ctx.check(self.ctx._lib.gp_small_size(self.h, C.byref(n), None, None))
+        return n.value
+
+    def get(self, g, what):
+        n = self.n
+        out = np.zeros(n) if what == L.GP_SMALL_GET_ALPHA else np.zeros((n, n), order="F")
+        self.ctx.check(self.ctx._lib.gp_small_get(self.h, int(g), what, L.dptr(out), n))
+        return out
+
+    def posterior(self, Xs):
+        """(mean[G, m], var[G, m]) of every model at every test point, one launch."""
+        Xs = L.f64(np.asarray(Xs, dtype=np.float64).reshape(-1, self.d))
+        m = Xs.shape[0]
+        mean, var = np.zeros((self.G, m)), np.zeros((self.G, m))
+        self.ctx.check(self.ctx._lib.gp_small_posterior(self.h, L.dptr(Xs), m, max(m, 1), L.dptr(mean), L.dptr(var)))
+        return mean, var
+
+    def ucb(self, Xs, kappa, g=0):
+        """(value[m], grad[m, d]) of mean + kappa sqrt(var) for model g."""
+        Xs = L.f64(np.asarray(Xs, dtype=np.float64).reshape(-1, self.d))
+        m = Xs.shape[0]
+        val, grad = np.zeros(m), np.zeros((m, self.d))
+        self.ctx.check(self.ctx._lib.gp_small_ucb(self.h, int(g), L.dptr(Xs), m, max(m, 1), float(kappa), L.dptr(val), L.dptr(grad)))
+        return val, grad
+
+    def append(self, x_new, y_new):
+        x_new = np.ascontiguousarray(x_new, dtype=np.float64).reshape(-1)
+        y_new = np.ascontiguousarray(np.atleast_1d(y_new), dtype=np.float64)
+        if x_new.size != self.d or y_new.size != self.G:
+            raise ValueError("dimension mismatch")
+        info = C.c_int()
+        self.ctx.check(self.ctx._lib.gp_small_append(self.h, L.dptr(x_new), L.dptr(y_new), C.byref(info)), info.value)
+
+    def maximize_ucb(self, starts, kappa, g=0, max_iter=10, history=4):
+        """(best_x[d], best_value, evaluations) over c lockstep L-BFGS runs."""
+        starts = L.f64(np.asarray(starts, dtype=np.float64).reshape(-1, self.d))
+        c = starts.shape[0]
+        bx, bv, ev = np.zeros(self.d), C.c_double(), C.c_int()
+        self.ctx.check(self.ctx._lib.gp_small_maximize_ucb(self.h, int(g), L.dptr(starts), c, c, float(kappa), int(max_iter), int(history),
+                                                           L.dptr(bx), C.byref(bv), C.byref(ev)))
+        return bx, bv.value, ev.value
+
+
 class DistGroup:
     """gp_dist_*: this rank's RCCL communicator on `ctx`'s device (one process per GPU).  `exchange(id_bytes_or_None) -> id_bytes`
     ships rank 0's 128-byte id to every rank (torch.distributed broadcast, a file, a socket ...)."""

@@ -374,6 +374,12 @@ void gpi_solve_rows_lower(gp_ctx *ctx, double *Vt, int mp, const double *L, int 
                           const double *tvec, double *dots) { solve_rows_lower(ctx, Vt, mp, L, np, ldl, dinv, sumsq, tvec, dots); }
 void gpi_inverse_transpose_lower(gp_ctx *ctx, double *T, const double *L, int np, int ldl, const double *dinv) { inverse_transpose_lower(ctx, T, L, np, ldl, dinv); }
 void gpi_back_solve_vec(gp_ctx *ctx, const double *L, int np, int ldl, const double *dinv, double *z, double *alpha) { back_solve_vec(ctx, L, np, ldl, dinv, z, alpha); }
+// alpha of a fitted model (computed on demand) copied into a caller's device buffer of n doubles
+gp_status gpi_model_alpha(gp_model *m, double *dst) {
+    ensure_alpha(m);
+    GP_HIP(m->ctx, hipMemcpyAsync(dst, m->dalpha, sizeof(double) * m->n, hipMemcpyDeviceToDevice, m->ctx->stream));
+    return GP_OK;
+}
 // k-th helper context of `ctx` (same device, own stream and workspaces), created on first use and destroyed with it
 gp_ctx *gpi_child_ctx(gp_ctx *ctx, int k) {
     ctx_ext *x = ext_of(ctx);

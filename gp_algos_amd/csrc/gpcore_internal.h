@@ -149,6 +149,7 @@ gp_status gpi_upload_2d(gp_ctx *ctx, double *dst, int ldd, const double *src, in
 gp_status gpi_download_2d(gp_ctx *ctx, double *dst, int ldd, const double *src, int lds, int rows, int cols);
 gp_status gpi_read_info(gp_ctx *ctx, int *info);
 gp_ctx *gpi_child_ctx(gp_ctx *ctx, int k);
+gp_status gpi_model_alpha(gp_model *m, double *dst);
 void gpi_chol_blocked(gp_ctx *ctx, double *A, int np, int lda, double *dinv, int extra);
 void gpi_solve_rows_lower(gp_ctx *ctx, double *Vt, int mp, const double *L, int np, int ldl, const double *dinv, double *sumsq,
                           const double *tvec = nullptr, double *dots = nullptr);

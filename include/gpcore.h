@@ -43,6 +43,7 @@ typedef struct gp_ctx gp_ctx;     /* device + stream + workspaces               
 typedef struct gp_model gp_model; /* fitted regression model: X, L, alpha resident in HBM          */
 typedef struct gp_ep gp_ep;       /* EP classification state: K, Sigma, L, site parameters in HBM  */
 typedef struct gp_dist gp_dist;   /* RCCL communicator of one rank (one process per GPU)           */
+typedef struct gp_small gp_small; /* G small GP models over one set of training inputs (GP-UCB, GP-UKF) */
 
 /* ---- library / context ------------------------------------------------------------------- */
 const char *gp_version(void);
@@ -194,6 +195,39 @@ gp_status gp_ep_predict(gp_ep *ep, const double *Ks, int m, int ldks, const doub
  * failing pivot of I + S^1/2 K S^1/2 with lml = NaN).  The reference's mis-keyed result map is not replicated. */
 gp_status gp_ep_lml_rbf_batched(gp_ctx *ctx, const double *X, int n, int d, int ldx, const int32_t *y, const double *thetas, int B, double stop_eps, int max_sweeps, int strict, double *lml, int *sweeps, int *info);
 void gp_ep_destroy(gp_ep *ep);
+
+/* ---- batched small-n posteriors: GP-UCB and GP-UKF --------------------------------------------- */
+/* The heaviest callers of GpPredictor.computePosterior (gp/regression/GpPredictor.scala:45-58) ask for ONE test point per call
+ * against a few hundred training points: GPOptimizer.maximizeUCB (gp/optimization/GPOptimizer.scala:82-109) inside L-BFGS, and
+ * the GP-UKF's transition / observation / noise functions (dynamicalsystems/filtering/GPUnscentedKalmanFilter.scala:72-93,138-147)
+ * once per sigma point, state dimension and time step.  A gp_small holds G models that share their training inputs X (one GP
+ * per output dimension, each with its own theta, L, L^-1 and alpha) so that all (model, test point) pairs of a call are ONE
+ * launch.  n and capacity are at most GP_SMALL_MAX_N. */
+#define GP_SMALL_MAX_N 2048
+/* GPUnscentedKalmanFilter.learnInputOutput (:116-129) / GPOptimizer.maximize's preComputeComponents (:51): fit G models on the
+ * shared inputs X (n x d); Y is n x G (column g = targets of model g), thetas G x (d+2) row-major.  `capacity` >= n reserves
+ * room for gp_small_append. */
+gp_status gp_small_fit(gp_ctx *ctx, const double *X, int n, int d, int ldx, const double *Y, int ldy, int G, const double *thetas, double sigma_noise, int capacity, gp_small **out, int *info);
+/* The same from factors the caller holds: Ls = G matrices (n x n, leading dimension ldl, model g at Ls + g*ldl*n), alphas G x n.
+ * Such a batch cannot be appended to (it carries no targets). */
+gp_status gp_small_from_factors(gp_ctx *ctx, const double *X, int n, int d, int ldx, const double *thetas, int G, const double *Ls, int ldl, const double *alphas, int capacity, gp_small **out);
+void gp_small_destroy(gp_small *small);
+gp_status gp_small_size(const gp_small *small, int *n, int *capacity, int *G);
+enum { GP_SMALL_GET_L = 0, GP_SMALL_GET_LINV = 1, GP_SMALL_GET_ALPHA = 2 };
+gp_status gp_small_get(gp_small *small, int g, int what, double *out, int ld);
+/* computePosterior(X, x*_i, L_g, alpha_g)._1.mean(0) and .sigma(0,0) for every model g and test point i in one launch:
+ * mean[g*m + i], var[g*m + i] (var = sf^2 + sn^2 - |L^-1 k*|^2, the diagonal the symmetric builder gives, :56). */
+gp_status gp_small_posterior(gp_small *small, const double *Xs, int m, int ldxs, double *mean, double *var);
+/* GPOptimizer.maximizeUCB's objective (:88-106) for model g at m candidate points: value[i] = mean + kappa*sqrt(var) and its
+ * gradient grad[i*d + k] w.r.t. the candidate, through GaussianRbfKernel.gradient (utils/KernelRequisites.scala:95-107). */
+gp_status gp_small_ucb(gp_small *small, int g, const double *Xs, int m, int ldxs, double kappa, double *value, double *grad);
+/* GPOptimizer.maximize (:47-72) appends the chosen point and REFITS (O(n^3)); this extends L, L^-1 and alpha of every model by
+ * the new row in O(n^2): x_new[d], y_new[G].  GP_ENOTPD (*info = n+1) leaves the batch unchanged. */
+gp_status gp_small_append(gp_small *small, const double *x_new, const double *y_new, int *info);
+/* The c L-BFGS runs of one GP-UCB iteration (GPOptimizer.scala:55-63; BreezeLbfgsOptimizer m = history, maxIter = max_iter,
+ * optimization/Optimization.scala:30-63) in lockstep: starts is c x d (leading dimension lds), all trial points of an iteration
+ * are evaluated in one launch.  best_x[d], *best_val: the best point and UCB value any evaluation saw. */
+gp_status gp_small_maximize_ucb(gp_small *small, int g, const double *starts, int c, int lds, double kappa, int max_iter, int history, double *best_x, double *best_val, int *evals_out);
 
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI ------------------------------------------- */
 /* The reference has no distributed code; these drive its two embarrassingly parallel loops: the settings that

@@ -322,6 +322,90 @@ done:
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* KernelRequisites.scala:95-107  GaussianRbfKernel.gradient(afterFirstArg)(vec1, vec2):        */
+/*   diff = vec1 - vec2;  a1 = apply(vec1, vec2, sameIndex = false);                            */
+/*   afterFirstArg ? (diff :* 1/(l*l)) :* (-a1) : (diff :* 1/(l*l)) :* a1                      */
+/* ------------------------------------------------------------------------------------------ */
+void orc_kernel_gradient(const double *v1, const double *v2, int d, const double *theta, int after_first, double *out) {
+    double a1 = rbf_apply(v1, 1, 0, v2, 1, 0, d, theta, 0);
+    for (int k = 0; k < d; ++k) {
+        double diff = v1[k] - v2[k];
+        double ls = theta[1 + k];
+        double inv = 1.0 / (ls * ls);
+        out[k] = after_first ? (diff * inv) * (-a1) : (diff * inv) * a1;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* gp/optimization/GPOptimizer.scala:82-109  maximizeUCB's funcForOptimizer at ONE test point:   */
+/*   (dist, v) = computePosterior(pointSet, x, ll, alphaVec)                    :91             */
+/*   ucb      = mean(0) + kParam * sqrt(sigma(0,0))                             :94             */
+/*   testTrainDer (d x n): column j = gradient(afterFirstArg = true)(x, X_j)    :95, :112-127   */
+/*   trainTestDer (n x d): row j    = gradient(afterFirstArg = false)(X_j, x)   :96             */
+/*   derAfterMean = testTrainDer * alphaVec                                     :97             */
+/*   derAfterVarFirst = gradient(true)(x, x)                                    :98             */
+/*   vAfterXDer = inversedL * trainTestDer   (inversedL = invTriangular(ll))    :85,:99         */
+/*   derAfterVar = derAfterVarFirst - (vAfterXDer^T * v) :* 2                   :101            */
+/*   ucbDer = derAfterMean + derAfterVar :* (kParam / (2 sqrt(sigma(0,0))))     :102-103        */
+/* X is n x d column-major (pointSet), x the test point (d).                                    */
+/* ------------------------------------------------------------------------------------------ */
+int orc_inv_triangular(const double *T, int n, int ldt, int is_upper, double *out, int ldo);
+int orc_ucb(const double *X, int n, int d, int ldx, const double *theta, const double *L, int ldl, const double *alpha,
+            const double *x, double kappa, double *value, double *grad) {
+    double *ks = (double *)malloc((size_t)n * sizeof(double)), *v = (double *)malloc((size_t)n * sizeof(double));
+    double *Li = (double *)malloc((size_t)n * n * sizeof(double));
+    double *tt = (double *)malloc((size_t)n * d * sizeof(double)), *vx = (double *)malloc((size_t)n * d * sizeof(double));
+    double *row = (double *)malloc((size_t)d * sizeof(double)), *g = (double *)malloc((size_t)d * sizeof(double));
+    if (!ks || !v || !Li || !tt || !vx || !row || !g) { free(ks); free(v); free(Li); free(tt); free(vx); free(row); free(g); return ORC_ENOMEM; }
+    /* computePosterior, m = 1 */
+    for (int j = 0; j < n; ++j) ks[j] = rbf_apply(x, 1, 0, X, ldx, j, d, theta, 0);
+    double mean = 0.0;
+    for (int j = 0; j < n; ++j) mean = mean + ks[j] * alpha[j];
+    for (int r = 0; r < n; ++r) {                      /* forwardSolve(L, k*)  MatrixUtils.scala:123-133 */
+        double acc = 0.0;
+        for (int c = 0; c < r; ++c) acc = acc + EL(L, ldl, r, c) * v[c];
+        v[r] = (ks[r] - acc) / EL(L, ldl, r, r);
+    }
+    double vv = 0.0;
+    for (int r = 0; r < n; ++r) vv = vv + v[r] * v[r];
+    double sigma = rbf_apply(x, 1, 0, x, 1, 0, d, theta, 1) - vv;     /* buildKernelMatrix(kernel, testData) has sn^2 on its diagonal */
+    *value = mean + kappa * sqrt(sigma);
+    int rc = orc_inv_triangular(L, n, ldl, 0, Li, n);
+    if (rc) { free(ks); free(v); free(Li); free(tt); free(vx); free(row); free(g); return rc; }
+    for (int k = 0; k < d; ++k) g[k] = 0.0;
+    double *xj = (double *)malloc((size_t)d * sizeof(double));
+    for (int j = 0; j < n; ++j) {
+        for (int k = 0; k < d; ++k) xj[k] = EL(X, ldx, j, k);
+        orc_kernel_gradient(xj, x, d, theta, 0, row);                    /* trainTestDer row j */
+        for (int k = 0; k < d; ++k) EL(tt, n, j, k) = row[k];
+    }
+    /* derAfterMean = testTrainDer * alpha, column-wise axpy (dgemv 'N'), j ascending */
+    for (int j = 0; j < n; ++j) {
+        for (int k = 0; k < d; ++k) xj[k] = EL(X, ldx, j, k);
+        orc_kernel_gradient(x, xj, d, theta, 1, row);                    /* testTrainDer column j */
+        for (int k = 0; k < d; ++k) g[k] = g[k] + row[k] * alpha[j];
+    }
+    /* vAfterXDer = inversedL * trainTestDer  (dgemm 'N','N': for each column, l ascending axpy) */
+    for (int k = 0; k < d; ++k) {
+        for (int i = 0; i < n; ++i) EL(vx, n, i, k) = 0.0;
+        for (int l = 0; l < n; ++l) {
+            double b = EL(tt, n, l, k);
+            for (int i = 0; i < n; ++i) EL(vx, n, i, k) = EL(vx, n, i, k) + EL(Li, n, i, l) * b;
+        }
+    }
+    orc_kernel_gradient(x, x, d, theta, 1, row);                          /* derAfterVarFirst (a vector of -0.0) */
+    double coeff = kappa / (2.0 * sqrt(sigma));
+    for (int k = 0; k < d; ++k) {
+        double dot = 0.0;
+        for (int i = 0; i < n; ++i) dot = dot + EL(vx, n, i, k) * v[i];
+        double der_var = row[k] - dot * 2.0;
+        grad[k] = g[k] + der_var * coeff;
+    }
+    free(xj); free(ks); free(v); free(Li); free(tt); free(vx); free(row); free(g);
+    return ORC_OK;
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* EpParameterEstimator.scala:98-109 marginalMoments                                            */
 /* ------------------------------------------------------------------------------------------ */
 static void marginal_moments(double cav_mi, double cav_sigma, int target, double *mi_hat, double *sigma_hat) {

@@ -202,6 +202,25 @@ def lml_grad(X, y, theta, nparams=None, sigma_noise=None):
     return out.value, grad
 
 
+def kernel_gradient(v1, v2, theta, after_first_arg):
+    """GaussianRbfKernel.gradient(afterFirstArg)(vec1, vec2), KernelRequisites.scala:95-107."""
+    v1, v2, theta = _f(v1), _f(v2), _f(theta)
+    out = np.zeros(v1.size)
+    lib().orc_kernel_gradient(_p(v1), _p(v2), _i(v1.size), _p(theta), _i(1 if after_first_arg else 0), _p(out))
+    return out
+
+
+def ucb(X, theta, L, alpha, x, kappa):
+    """GPOptimizer.maximizeUCB's objective and gradient at one test point (GPOptimizer.scala:82-109): (value, grad[d])."""
+    X, theta, L, alpha, x = _f(X), _f(theta), _f(L), _f(alpha), _f(x)
+    n, d = X.shape
+    val = _d()
+    grad = np.zeros(d)
+    rc = lib().orc_ucb(_p(X), _i(n), _i(d), _ld(X), _p(theta), _p(L), _ld(L), _p(alpha), _p(x), _d(float(kappa)), C.byref(val), _p(grad))
+    assert rc == 0
+    return val.value, grad
+
+
 def marginal_moments(cav_mi, cav_sigma, target):
     a, b = _d(), _d()
     lib().orc_marginal_moments(_d(cav_mi), _d(cav_sigma), _i(int(target)), C.byref(a), C.byref(b))

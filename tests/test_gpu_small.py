@@ -1,0 +1,166 @@
+"""Batched small-n posterior workloads through the C-ABI (gp_small_*), against the oracle's restatement of
+  GpPredictor.computePosterior with one test point            gp/regression/GpPredictor.scala:45-58
+  GPOptimizer.maximizeUCB's objective and gradient            gp/optimization/GPOptimizer.scala:82-109
+  GaussianRbfKernel.gradient                                  utils/KernelRequisites.scala:95-107
+and, for the rank-1 append, against a REFIT on the extended data (what GPOptimizer.maximize does per iteration, :51)."""
+import numpy as np
+import pytest
+
+from gp_algos_amd import _lib as L
+from gp_algos_amd import synth
+from oracle import gp_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from gp_algos_amd.core import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def _models(n, d, G, seed):
+    p = synth.regression(n, d, 20, seed, seed + 1, seed + 2, synth.ard_theta(d, 1.2, 1.0, 0.15))
+    rng = np.random.default_rng(seed)
+    thetas = p["theta"][None, :] * rng.uniform(0.7, 1.5, size=(G, d + 2))
+    Y = np.asfortranarray(np.stack([p["y"] * (1.0 + 0.3 * g) + 0.2 * np.sin((g + 1) * p["X"][:, 0]) for g in range(G)], axis=1))
+    return p, thetas, Y
+
+
+@pytest.mark.parametrize("n,d,G,m", [(1, 1, 1, 1), (37, 1, 2, 3), (150, 2, 3, 9), (200, 4, 4, 9), (300, 8, 2, 17)])
+def test_small_batch_fit_and_posterior_vs_oracle(ctx, n, d, G, m):
+    """GP-UKF shape: G models (one per state dimension) over the same inputs, 2 D + 1 sigma points, mean(0) and sigma(0,0) each."""
+    from gp_algos_amd.core import SmallModelBatch
+    p, thetas, Y = _models(n, d, G, seed=3 * n + d)
+    sb = SmallModelBatch(ctx, p["X"], thetas, Y=Y)
+    Xs = p["Xs"][:m]
+    mean, var = sb.posterior(Xs)
+    assert mean.shape == (G, m)
+    for g in range(G):
+        Lo, ao = orc.fit(p["X"], Y[:, g], thetas[g])
+        assert np.max(np.abs(sb.get(g, L.GP_SMALL_GET_L) - Lo)) <= 1e-10 * np.max(np.abs(Lo))
+        assert np.max(np.abs(sb.get(g, L.GP_SMALL_GET_ALPHA) - ao)) <= 1e-8 * np.max(np.abs(ao))
+        Linv = orc.inv_triangular(Lo, False)
+        assert np.max(np.abs(sb.get(g, L.GP_SMALL_GET_LINV) - Linv)) <= 1e-9 * np.max(np.abs(Linv))
+        for i in range(m):      # one test point per computePosterior call, as the filter does
+            om, ov, _, _ = orc.predict(p["X"], thetas[g], Lo, ao, np.asfortranarray(Xs[i:i + 1]))
+            assert abs(mean[g, i] - om[0]) <= 1e-9 * max(1.0, abs(om[0]))
+            assert abs(var[g, i] - ov[0]) <= 1e-9 * thetas[g][0] ** 2
+    sb.close()
+
+
+def test_small_batch_from_caller_held_factors(ctx):
+    from gp_algos_amd.core import SmallModelBatch
+    p, thetas, Y = _models(120, 3, 3, seed=77)
+    facs = [orc.fit(p["X"], Y[:, g], thetas[g]) for g in range(3)]
+    sb = SmallModelBatch(ctx, p["X"], thetas, Ls=[f[0] for f in facs], alphas=[f[1] for f in facs])
+    mean, var = sb.posterior(p["Xs"])
+    for g in range(3):
+        om, ov, _, _ = orc.predict(p["X"], thetas[g], facs[g][0], facs[g][1], p["Xs"])
+        assert np.max(np.abs(mean[g] - om)) <= 1e-9 * max(1.0, np.max(np.abs(om)))
+        assert np.max(np.abs(var[g] - ov)) <= 1e-9 * thetas[g][0] ** 2
+    with pytest.raises(ValueError):
+        sb.append(p["Xs"][0], np.zeros(3))          # no targets were given: alpha cannot be extended
+    sb.close()
+
+
+@pytest.mark.parametrize("n,d", [(30, 1), (120, 3), (250, 8)])
+def test_ucb_value_and_input_gradient_vs_oracle(ctx, n, d):
+    """A4 on the device: GaussianRbfKernel.gradient inside GPOptimizer.maximizeUCB's objective (GPOptimizer.scala:88-106)."""
+    from gp_algos_amd.core import SmallModelBatch
+    p, thetas, Y = _models(n, d, 2, seed=11 * n)
+    sb = SmallModelBatch(ctx, p["X"], thetas, Y=Y)
+    kappa = 1.7
+    for g in range(2):
+        Lo, ao = orc.fit(p["X"], Y[:, g], thetas[g])
+        val, grad = sb.ucb(p["Xs"][:6], kappa, g=g)
+        for i in range(6):
+            ov, og = orc.ucb(p["X"], thetas[g], Lo, ao, p["Xs"][i], kappa)
+            assert abs(val[i] - ov) <= 1e-9 * max(1.0, abs(ov))
+            assert np.max(np.abs(grad[i] - og)) <= 1e-8 * max(1.0, np.max(np.abs(og)))
+    # the kernel gradient itself (KernelRequisites.scala:95-107) against its mirror
+    from gp_algos_amd.utils.kernel_requisites import GaussianRbfKernel, GaussianRbfParams
+    th = thetas[0]
+    kern = GaussianRbfKernel(GaussianRbfParams(signalVar=th[0], lengthScales=th[1:-1], noiseVar=th[-1]))
+    for first in (True, False):
+        np.testing.assert_allclose(kern.gradient(first)(p["X"][0], p["Xs"][0]), orc.kernel_gradient(p["X"][0], p["Xs"][0], th, first), rtol=1e-14)
+    sb.close()
+
+
+def test_rank_one_append_equals_refit(ctx):
+    """GPOptimizer.maximize refits after every appended point (GPOptimizer.scala:51,64-67); the O(n^2) extension must give the
+    factor, alpha and posterior of that refit."""
+    from gp_algos_amd._lib import NotPositiveDefinite
+    from gp_algos_amd.core import SmallModelBatch
+    p, thetas, Y = _models(75, 2, 2, seed=5)
+    n0 = 60
+    sb = SmallModelBatch(ctx, p["X"][:n0], thetas, Y=Y[:n0], capacity=80)
+    for k in range(n0, 75):
+        sb.append(p["X"][k], Y[k])
+        assert sb.n == k + 1
+    mean, var = sb.posterior(p["Xs"])
+    for g in range(2):
+        Lo, ao = orc.fit(p["X"][:75], Y[:75, g], thetas[g])
+        assert np.max(np.abs(sb.get(g, L.GP_SMALL_GET_L) - Lo)) <= 1e-10 * np.max(np.abs(Lo))
+        assert np.max(np.abs(sb.get(g, L.GP_SMALL_GET_ALPHA) - ao)) <= 1e-8 * np.max(np.abs(ao))
+        om, ov, _, _ = orc.predict(p["X"][:75], thetas[g], Lo, ao, p["Xs"])
+        assert np.max(np.abs(mean[g] - om)) <= 1e-9 * max(1.0, np.max(np.abs(om)))
+        assert np.max(np.abs(var[g] - ov)) <= 1e-9 * thetas[g][0] ** 2
+    # five more fill the capacity; the sixth is refused
+    for k in range(5):
+        sb.append(p["Xs"][k], np.array([0.1, -0.2]))
+    with pytest.raises(ValueError):
+        sb.append(p["Xs"][6], np.array([0.0, 0.0]))
+    sb.close()
+    # a duplicated point without noise: the extended matrix is singular, lambda^2 = sf^2 - |l|^2 is zero up to rounding.  Whichever
+    # side of zero it lands on, the outcome is consistent: refused with the failing pivot n + 1 and nothing changed, or accepted
+    # with a vanishing pivot (exactly what a refit's dpotf2 does with that matrix)
+    th0 = thetas[:1].copy()
+    th0[0, -1] = 0.0
+    sb = SmallModelBatch(ctx, p["X"][:20], th0, Y=Y[:20, :1], capacity=30)
+    before = sb.get(0, L.GP_SMALL_GET_ALPHA)
+    try:
+        sb.append(p["X"][3], np.array([Y[3, 0]]))
+        assert sb.n == 21 and sb.get(0, L.GP_SMALL_GET_L)[20, 20] <= 1e-6 * th0[0, 0]
+    except NotPositiveDefinite as e:
+        assert e.info == 21 and sb.n == 20 and np.array_equal(sb.get(0, L.GP_SMALL_GET_ALPHA), before)
+    sb.close()
+
+
+def test_lockstep_lbfgs_over_the_ucb_surface(ctx):
+    """The c L-BFGS runs of one GP-UCB iteration (GPOptimizer.scala:55-63) in lockstep: the returned point is at least as good as
+    every start, is a stationary point of the oracle's objective, and matches scipy's L-BFGS run on the oracle from the best start."""
+    import scipy.optimize as so
+    from gp_algos_amd.core import SmallModelBatch
+    p, thetas, Y = _models(90, 2, 1, seed=21)
+    sb = SmallModelBatch(ctx, p["X"], thetas, Y=Y)
+    Lo, ao = orc.fit(p["X"], Y[:, 0], thetas[0])
+    kappa = 2.0
+    starts = np.asfortranarray(p["Xs"][:5])
+    v0, _ = sb.ucb(starts, kappa)
+    bx, bv, evals = sb.maximize_ucb(starts, kappa, max_iter=30, history=4)
+    assert bv >= np.max(v0) - 1e-12 and evals >= 5
+    ov, og = orc.ucb(p["X"], thetas[0], Lo, ao, bx, kappa)
+    assert abs(ov - bv) <= 1e-9 * max(1.0, abs(ov))
+    ref = max((so.minimize(lambda x: tuple(-t for t in orc.ucb(p["X"], thetas[0], Lo, ao, x, kappa)), s, jac=True, method="L-BFGS-B",
+                           options=dict(maxiter=200, maxcor=4)) for s in starts), key=lambda r: -r.fun)
+    assert bv >= -ref.fun - 1e-5 * max(1.0, abs(ref.fun))
+    sb.close()
+
+
+def test_small_batch_argument_errors(ctx):
+    from gp_algos_amd.core import SmallModelBatch
+    p, thetas, Y = _models(20, 2, 2, seed=9)
+    with pytest.raises(ValueError):
+        SmallModelBatch(ctx, p["X"], thetas[:, :-1], Y=Y)              # theta length != d + 2
+    with pytest.raises(ValueError):
+        SmallModelBatch(ctx, p["X"], thetas, Y=Y[:, :1])               # one target column per model
+    big = np.zeros((L.GP_SMALL_MAX_N + 1, 1), order="F")
+    with pytest.raises(ValueError):
+        SmallModelBatch(ctx, big, np.array([[1.0, 1.0, 0.1]]), Y=np.zeros((L.GP_SMALL_MAX_N + 1, 1)))
+    sb = SmallModelBatch(ctx, p["X"], thetas, Y=Y)
+    with pytest.raises(ValueError):
+        sb.ucb(p["Xs"][:2], 1.0, g=5)
+    sb.close()
