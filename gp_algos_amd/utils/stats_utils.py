@@ -1,4 +1,5 @@
-"""Mirror of the hot-path part of utils/StatsUtils.scala (:13-25)."""
+"""Mirror of the hot-path part of utils/StatsUtils.scala (:13-25) and of meanAndVarOfData (:59-71), which GP-UCB uses to place
+its L-BFGS starting points."""
 import math
 from dataclasses import dataclass
 
@@ -21,3 +22,18 @@ class GaussianDistribution:
     @property
     def dim(self):
         return int(np.asarray(self.mean).size)
+
+
+def meanAndVarOfData(data):
+    """/*data(i,::) - ith sample*/  StatsUtils.scala:59-71: (mean, covariance with the 1/N normalisation)."""
+    data = np.asarray(data, dtype=np.float64)
+    n = data.shape[0]
+    mean = np.zeros(data.shape[1])
+    for i in range(n):
+        mean = mean + data[i, :]
+    mean = mean / float(n)
+    cov = np.zeros((data.shape[1], data.shape[1]))
+    for i in range(n):
+        diff = data[i, :] - mean
+        cov = cov + np.outer(diff, diff)
+    return mean, cov / float(n)

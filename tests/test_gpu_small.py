@@ -164,3 +164,76 @@ def test_small_batch_argument_errors(ctx):
     with pytest.raises(ValueError):
         sb.ucb(p["Xs"][:2], 1.0, g=5)
     sb.close()
+
+
+# ---- the reference's callers, mirrored --------------------------------------------------------------------------------------
+def _rbf_predictor(d, sf=1.0, ell=1.0, sn=0.1):
+    from gp_algos_amd.gp.regression.gp_predictor import GpPredictor
+    from gp_algos_amd.utils.kernel_requisites import GaussianRbfKernel, GaussianRbfParams
+    return GpPredictor(GaussianRbfKernel(GaussianRbfParams(signalVar=sf, lengthScales=ell * np.ones(d), noiseVar=sn)))
+
+
+def test_gp_optimizer_mirror_grid_and_quadratic(ctx):
+    """GPOptimizerTest.scala:33-52: the initial grid has 3*dim rows inside the ranges; a simple 1-D function is optimised."""
+    import gp_algos_amd
+    from gp_algos_amd.gp.optimization.gp_optimizer import GPOInput, GPOptimizer
+    gp_algos_amd.set_default_context(ctx)
+    opt = GPOptimizer(_rbf_predictor(1, sf=3.0, ell=2.0, sn=0.05), noise=None, gradientOptimizer=None, seed=4)
+    inp = GPOInput(ranges=[range(-6, 7)], mParam=25, cParam=5, kParam=2.0)
+    grid = opt.prepareGrid(inp.ranges)
+    assert grid.shape == (3, 1) and np.all(grid > -6) and np.all(grid < 6)
+    f = lambda x: (x[0] - 1.5) ** 2 - 3.0                                    # minimum -3 at 1.5
+    x, v = opt.minimize(f, inp)
+    assert abs(x[0] - 1.5) <= 0.15 and v <= -3.0 + 0.03
+    # two dimensions
+    opt2 = GPOptimizer(_rbf_predictor(2, sf=3.0, ell=1.5, sn=0.05), seed=7)
+    # (the prior mean is zero and nothing confines the search to the ranges -- as in the reference -- so far from the data the
+    # bound is k*sf: an objective whose optimum lies below that sends every iteration outwards; this one peaks at 10 > 2*3)
+    g = lambda x: 10.0 - ((x[0] - 0.5) ** 2 + (x[1] + 1.0) ** 2)
+    x2, v2 = opt2.maximize(g, GPOInput(ranges=[range(-3, 4), range(-3, 4)], mParam=40, cParam=6, kParam=2.0))
+    assert v2 >= 10.0 - 0.15 and np.hypot(x2[0] - 0.5, x2[1] + 1.0) <= 0.4
+    # hyper-parameters fitted on the 3*dim initial points first (the rastrigin case of the reference's test, which only prints):
+    # it runs, evaluates m more points and returns the best evaluated one
+    calls = []
+    h = lambda x: (calls.append(1), g(x))[1]
+    x3, v3 = opt2.maximize(h, GPOInput(ranges=[range(-3, 4), range(-3, 4)], mParam=10, cParam=4, kParam=2.0, optimizeHpOnInitGrid=True))
+    assert len(calls) == 6 + 10 and abs(g(x3) - v3) <= 1e-15
+    with pytest.raises(ValueError):
+        opt.maximize(f, GPOInput(ranges=[range(-6, 7)], mParam=0, cParam=5, kParam=2.0))
+
+
+def test_gp_ssm_model_batched_sigma_points_vs_per_call_posterior(ctx):
+    """GPUnscentedKalmanFilter.scala:72-87,138-147: transition / observation / noise functions over a sigma-point set against the
+    reference's own call pattern -- computePosterior with one test point per (dimension, sigma point), here through the oracle."""
+    import gp_algos_amd
+    from gp_algos_amd.dynamicalsystems.filtering.gp_ssm_model import GpSsmModel
+    gp_algos_amd.set_default_context(ctx)
+    rng = np.random.default_rng(3)
+    D, O, T = 3, 2, 80
+    H = np.zeros((D, T))
+    for t in range(1, T):
+        H[:, t] = 0.9 * H[:, t - 1] + 0.3 * np.sin(H[::-1, t - 1]) + 0.2 * rng.standard_normal(D)
+    Obs = np.stack([H[0] * H[1] + 0.1 * rng.standard_normal(T), np.cos(H[2]) + 0.1 * rng.standard_normal(T)])
+    pred = _rbf_predictor(D, sf=1.2, ell=1.4, sn=0.15)
+    model = GpSsmModel.learn(pred, Obs, H)
+    theta = pred.kernelFunc.hyperParams.toDenseVector()
+    sigma_points = 0.5 * rng.standard_normal((2 * D + 1, D))
+    nxt, obs = model.transitionFuncImpl(sigma_points), model.observationFuncImpl(sigma_points)
+    Q, R = model.qNoise(sigma_points[0]), model.rNoise(sigma_points[0])
+    sysX, obsX = np.asfortranarray(H[:, :-1].T), np.asfortranarray(H.T)
+    for dim in range(D):
+        Lo, ao = orc.fit(sysX, (H[:, 1:] - H[:, :-1])[dim], theta)
+        for i, sp in enumerate(sigma_points):
+            om, ov, _, _ = orc.predict(sysX, theta, Lo, ao, np.asfortranarray(sp[None, :]))
+            assert abs(nxt[i, dim] - (sp[dim] + om[0])) <= 1e-9 * max(1.0, abs(om[0]))
+            if i == 0:
+                assert abs(Q[dim, dim] - ov[0]) <= 1e-9 * theta[0] ** 2
+    for dim in range(O):
+        Lo, ao = orc.fit(obsX, Obs[dim], theta)
+        for i, sp in enumerate(sigma_points):
+            om, ov, _, _ = orc.predict(obsX, theta, Lo, ao, np.asfortranarray(sp[None, :]))
+            assert abs(obs[i, dim] - om[0]) <= 1e-9 * max(1.0, abs(om[0]))
+            if i == 0:
+                assert abs(R[dim, dim] - ov[0]) <= 1e-9 * theta[0] ** 2
+    assert Q.shape == (D, D) and R.shape == (O, O) and np.count_nonzero(Q - np.diag(np.diag(Q))) == 0
+    model.close()
