@@ -68,6 +68,8 @@ SIGNATURES = {
     "gp_ep_get": (_i, [_vp, _i, _dp, _i]),
     "gp_ep_predict": (_i, [_vp, _dp, _i, _i, _dp, _dp]),
     "gp_ep_lml_rbf_batched": (_i, [_vp, _dp, _i, _i, _i, C.POINTER(C.c_int32), _dp, _i, _d, _i, _i, _dp, _ip, _ip]),
+    "gp_ep_lml_grad_rbf_batched": (_i, [_vp, _dp, _i, _i, _i, C.POINTER(C.c_int32), _dp, _i, _d, _i, _i, _dp, _dp, _ip, _ip]),
+    "gp_ep_optimize_rbf": (_i, [_vp, _dp, _i, _i, _i, C.POINTER(C.c_int32), _dp, _d, _i, _i, _i, _i, _dp, _dp, _ip, _ip]),
     "gp_ep_destroy": (None, [_vp]),
     "gp_small_fit": (_i, [_vp, _dp, _i, _i, _i, _dp, _i, _i, _dp, _d, _i, C.POINTER(_vp), _ip]),
     "gp_small_from_factors": (_i, [_vp, _dp, _i, _i, _i, _dp, _i, _dp, _i, _dp, _i, C.POINTER(_vp)]),

@@ -211,6 +211,37 @@ class Context:
                                                    sw.ctypes.data_as(C.POINTER(C.c_int)), info.ctypes.data_as(C.POINTER(C.c_int))))
         return lml, sw, info
 
+    def ep_lml_grad_rbf_batched(self, X, y, thetas, stop_eps=0.01, max_sweeps=1000, strict=True):
+        """gp_ep_lml_grad_rbf_batched: (lml[B], grad[B, d+2], sweeps[B], info[B])."""
+        X = L.f64(X)
+        n, d = X.shape
+        yi = np.ascontiguousarray(y, dtype=np.int32).reshape(-1)
+        thetas = np.ascontiguousarray(np.atleast_2d(thetas), dtype=np.float64)
+        B, P = thetas.shape
+        if P != d + 2 or yi.size != n:
+            raise ValueError("dimension mismatch")
+        lml, grad = np.zeros(B), np.zeros((B, P))
+        sw, info = np.zeros(B, dtype=np.int32), np.zeros(B, dtype=np.int32)
+        self.check(self._lib.gp_ep_lml_grad_rbf_batched(self.h, L.dptr(X), n, d, n, yi.ctypes.data_as(C.POINTER(C.c_int32)), L.dptr(thetas), B,
+                                                        float(stop_eps), int(max_sweeps), int(bool(strict)), L.dptr(lml), L.dptr(grad),
+                                                        sw.ctypes.data_as(C.POINTER(C.c_int)), info.ctypes.data_as(C.POINTER(C.c_int))))
+        return lml, grad, sw, info
+
+    def ep_optimize_rbf(self, X, y, theta0, stop_eps=0.01, max_sweeps=1000, strict=True, max_iter=10, history=4):
+        """gp_ep_optimize_rbf: (theta*, EP LML(theta*), iterations, evaluations)."""
+        X = L.f64(X)
+        n, d = X.shape
+        yi = np.ascontiguousarray(y, dtype=np.int32).reshape(-1)
+        theta0 = np.ascontiguousarray(theta0, dtype=np.float64)
+        if theta0.size != d + 2 or yi.size != n:
+            raise ValueError("dimension mismatch")
+        out, lml = np.zeros(d + 2), np.zeros(1)
+        its, evs = C.c_int(0), C.c_int(0)
+        self.check(self._lib.gp_ep_optimize_rbf(self.h, L.dptr(X), n, d, n, yi.ctypes.data_as(C.POINTER(C.c_int32)), L.dptr(theta0), float(stop_eps),
+                                                int(max_sweeps), int(bool(strict)), int(max_iter), int(history), L.dptr(out), L.dptr(lml),
+                                                C.byref(its), C.byref(evs)))
+        return out, float(lml[0]), its.value, evs.value
+
     def optimize_rbf(self, X, y, theta0, nparams=None, sigma_noise=None, max_iter=20, history=4):
         """gp_optimize_rbf: (theta*, LML(theta*), iterations, evaluations)."""
         X, y = L.f64(X), L.f64(y)

@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <functional>
 #include <new>
 #include <thread>
 
@@ -1312,27 +1313,17 @@ double vdot(const std::vector<double> &a, const std::vector<double> &b) {
 
 }  // namespace
 
-extern "C" gp_status gp_optimize_rbf(gp_ctx *ctx, const double *X, int n, int d, int ldx, const double *y, const double *theta0, int nparams,
-                                     double sigma_noise, int max_iter, int history, double *theta_out, double *lml_out, int *iters_out,
-                                     int *evals_out) {
-    if (!ctx) return GP_EINVAL;
-    GP_REQUIRE(ctx, X && y && theta0 && theta_out, "null pointer");
-    GP_REQUIRE(ctx, n >= 1 && d >= 1 && d <= 64 && ldx >= n, "bad dimensions");
-    const int P = d + 2;
-    GP_REQUIRE(ctx, nparams >= 1 && nparams <= P && max_iter >= 0 && history >= 1, "1 <= nparams <= d+2, max_iter >= 0, history >= 1");
-    GP_HIP(ctx, hipSetDevice(ctx->device));
-    constexpr int NC = 6;   // trial steps per iteration: alpha0, alpha0/2, ..., alpha0/32
-    lml_worker w;
-    w.ctx = ctx;
-    w.G = NC;
-    GP_TRY(lml_worker_setup(w, X, n, d, ldx, y, nparams));
-
+// Shared driver: maximise F over the first nparams entries of theta.  `evaluate(thetas, count, f, g, bad)` fills, for `count`
+// settings (rows of P doubles), f = F, g = dF/dtheta (count x nparams) and bad[c] != 0 where F is undefined (not positive definite).
+gp_status gpi_lbfgs_maximize(gp_ctx *ctx, int P, int nparams, const double *theta0, int max_iter, int history, int NC,
+                             const std::function<gp_status(const double *, int, double *, double *, int *)> &evaluate_raw,
+                             double *theta_out, double *f_out, int *iters_out, int *evals_out) {
     std::vector<double> theta(theta0, theta0 + P), thetas((size_t)NC * P), fl(NC), gl((size_t)NC * nparams);
     std::vector<int> infos(NC);
     int evals = 0;
-    // f = -LML, g = -grad at `count` settings; non-PD settings come back as +inf
+    // f = -F, g = -grad at `count` settings; undefined settings come back as +inf
     auto evaluate = [&](int count) -> gp_status {
-        GP_TRY(lml_worker_eval(w, thetas.data(), count, nparams, sigma_noise, fl.data(), gl.data(), infos.data()));
+        GP_TRY(evaluate_raw(thetas.data(), count, fl.data(), gl.data(), infos.data()));
         evals += count;
         for (int c = 0; c < count; ++c) {
             bool bad = infos[c] != 0 || !std::isfinite(fl[c]);
@@ -1410,10 +1401,30 @@ extern "C" gp_status gp_optimize_rbf(gp_ctx *ctx, const double *X, int n, int d,
     }
     std::copy(theta.begin(), theta.end(), theta_out);
     for (int i = 0; i < nparams; ++i) theta_out[i] = best_x[i];
-    if (lml_out) *lml_out = -best_f;
+    if (f_out) *f_out = -best_f;
     if (iters_out) *iters_out = it;
     if (evals_out) *evals_out = evals;
     return GP_OK;
+}
+
+extern "C" gp_status gp_optimize_rbf(gp_ctx *ctx, const double *X, int n, int d, int ldx, const double *y, const double *theta0, int nparams,
+                                     double sigma_noise, int max_iter, int history, double *theta_out, double *lml_out, int *iters_out,
+                                     int *evals_out) {
+    if (!ctx) return GP_EINVAL;
+    GP_REQUIRE(ctx, X && y && theta0 && theta_out, "null pointer");
+    GP_REQUIRE(ctx, n >= 1 && d >= 1 && d <= 64 && ldx >= n, "bad dimensions");
+    const int P = d + 2;
+    GP_REQUIRE(ctx, nparams >= 1 && nparams <= P && max_iter >= 0 && history >= 1, "1 <= nparams <= d+2, max_iter >= 0, history >= 1");
+    GP_HIP(ctx, hipSetDevice(ctx->device));
+    constexpr int NC = 6;   // trial steps per iteration: alpha0, alpha0/2, ..., alpha0/32
+    lml_worker w;
+    w.ctx = ctx;
+    w.G = NC;
+    GP_TRY(lml_worker_setup(w, X, n, d, ldx, y, nparams));
+    auto evaluate = [&](const double *thetas, int count, double *f, double *g, int *bad) -> gp_status {
+        return lml_worker_eval(w, thetas, count, nparams, sigma_noise, f, g, bad);
+    };
+    return gpi_lbfgs_maximize(ctx, P, nparams, theta0, max_iter, history, NC, evaluate, theta_out, lml_out, iters_out, evals_out);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -683,21 +683,31 @@ gp_status gp_ep_lml(gp_ep *ep, int strict, double *lml) {
     return gpi_download_2d(ctx, lml, 1, ctx->d_scalars, 1, 1, 1);
 }
 
+static gp_status ep_lml_grad_dev(gp_ep *ep, const double *dX, int d, const double *theta, int strict, double *grad);
+
 gp_status gp_ep_lml_grad_rbf(gp_ep *ep, const double *X, int d, int ldx, const double *theta, int strict, double *grad) {
     if (!ep) return GP_EINVAL;
     gp_ctx *ctx = ep->ctx;
-    const int n = ep->n, np = ep->np;
+    const int n = ep->n;
     GP_REQUIRE(ctx, X && theta && grad && d >= 1 && d <= 64 && ldx >= n, "bad arguments (1 <= d <= 64)");
     GP_REQUIRE(ctx, ep->sweeps > 0, "no sweep has run yet");
     GP_HIP(ctx, hipSetDevice(ctx->device));
+    double *dX;
+    GP_TRY(gpi_ws_get(ctx, WS_A, sizeof(double) * (size_t)n * d, &dX));
+    GP_TRY(gpi_upload_2d(ctx, dX, n, X, ldx, n, d));
+    return ep_lml_grad_dev(ep, dX, d, theta, strict, grad);
+}
+
+// the same with the training inputs already in HBM (n x d, ld = n)
+static gp_status ep_lml_grad_dev(gp_ep *ep, const double *dX, int d, const double *theta, int strict, double *grad) {
+    gp_ctx *ctx = ep->ctx;
+    const int n = ep->n, np = ep->np;
     hipStream_t s = ctx->stream;
     const int P = d + 2;
-    double *dX, *partial, *parts, *dres;
-    GP_TRY(gpi_ws_get(ctx, WS_A, sizeof(double) * (size_t)n * d, &dX));
-    GP_TRY(gpi_ws_get(ctx, WS_PARTIAL, sizeof(double) * (size_t)16 * np, &partial));
+    double *partial, *parts, *dres;
+    GP_TRY(gpi_ws_get(ctx, WS_PARTIAL, sizeof(double) * (size_t)(SYMV_CHUNKS + 1) * np, &partial));
     GP_TRY(gpi_ws_get(ctx, WS_SUMSQ, sizeof(double) * (size_t)gpk_lml_grad_partials_size(n, d), &parts));
     GP_TRY(gpi_ws_get(ctx, WS_C, sizeof(double) * (size_t)(P + 1), &dres));
-    GP_TRY(gpi_upload_2d(ctx, dX, n, X, ldx, n, d));
     double *t1 = ep->tmp1(), *t2 = ep->tmp2();
     // rhs = S^1/2 K nu                                                    MarginalLikelihoodEvaluator.scala:53-54
     gpk_gemv_rows(s, ep->K, n, n, np, ep->nu(), t1, partial, 16);
@@ -786,8 +796,44 @@ gp_status gp_ep_predict(gp_ep *ep, const double *Ks, int m, int ldks, const doub
 // setting index (the reference's map is mis-keyed).  Per setting: Gram on the device, EP sweeps until
 // AvgBasedStopCriterion(stop_eps) holds (EpParameterEstimator.scala:187-202; sweep 0 always runs; stop_eps < 0: exactly
 // max_sweeps sweeps), EP LML (strict: as compiled).  Settings are independent: a few run concurrently, each on its own context.
+static gp_status ep_eval_batched(gp_ctx *ctx, const double *X, int n, int d, int ldx, const int32_t *y, const double *thetas, int B,
+                                 double stop_eps, int max_sweeps, int strict, double *lml, double *grad, int *sweeps, int *info);
+
 gp_status gp_ep_lml_rbf_batched(gp_ctx *ctx, const double *X, int n, int d, int ldx, const int32_t *y, const double *thetas, int B,
                                 double stop_eps, int max_sweeps, int strict, double *lml, int *sweeps, int *info) {
+    return ep_eval_batched(ctx, X, n, d, ldx, y, thetas, B, stop_eps, max_sweeps, strict, lml, nullptr, sweeps, info);
+}
+
+// MarginalLikelihoodEvaluator.logLikelihood (gp/classification/MarginalLikelihoodEvaluator.scala:33-44) at B settings: EP log
+// marginal likelihood AND its gradient w.r.t. all d+2 hyper-parameters (:46-66), grad B x (d+2) row-major.
+gp_status gp_ep_lml_grad_rbf_batched(gp_ctx *ctx, const double *X, int n, int d, int ldx, const int32_t *y, const double *thetas, int B,
+                                     double stop_eps, int max_sweeps, int strict, double *lml, double *grad, int *sweeps, int *info) {
+    if (!ctx) return GP_EINVAL;
+    GP_REQUIRE(ctx, grad, "null gradient");
+    return ep_eval_batched(ctx, X, n, d, ldx, y, thetas, B, stop_eps, max_sweeps, strict, lml, grad, sweeps, info);
+}
+
+// GradientHyperParamsOptimizer.optimizeHyperParams (gp/classification/HyperParamsOptimization.scala:31-55): maximise the EP log
+// marginal likelihood over all d+2 hyper-parameters with the gradient-based optimiser it is wired with -- BreezeLbfgsOptimizer
+// (optimization/Optimization.scala:30-63: L-BFGS m = history, maxIter, best-seen point).  Every objective evaluation is a full
+// EP run (Gram -> sweeps until AvgBasedStopCriterion(stop_eps) or max_sweeps -> LML + gradient); the trial steps of one line
+// search are independent EP problems and run concurrently on the context's helper contexts.
+gp_status gp_ep_optimize_rbf(gp_ctx *ctx, const double *X, int n, int d, int ldx, const int32_t *y, const double *theta0, double stop_eps,
+                             int max_sweeps, int strict, int max_iter, int history, double *theta_out, double *lml_out, int *iters_out,
+                             int *evals_out) {
+    if (!ctx) return GP_EINVAL;
+    GP_REQUIRE(ctx, X && y && theta0 && theta_out, "null pointer");
+    GP_REQUIRE(ctx, n >= 1 && d >= 1 && d <= 64 && ldx >= n && max_sweeps >= 1 && max_iter >= 0 && history >= 1, "bad arguments");
+    const int P = d + 2;
+    constexpr int NC = 3;   // trial steps per iteration = concurrent EP problems (GPCORE_EP_WORKERS)
+    auto evaluate = [&](const double *thetas, int count, double *f, double *g, int *bad) -> gp_status {
+        return ep_eval_batched(ctx, X, n, d, ldx, y, thetas, count, stop_eps, max_sweeps, strict, f, g, nullptr, bad);
+    };
+    return gpi_lbfgs_maximize(ctx, P, P, theta0, max_iter, history, NC, evaluate, theta_out, lml_out, iters_out, evals_out);
+}
+
+static gp_status ep_eval_batched(gp_ctx *ctx, const double *X, int n, int d, int ldx, const int32_t *y, const double *thetas, int B,
+                                 double stop_eps, int max_sweeps, int strict, double *lml, double *grad, int *sweeps, int *info) {
     if (!ctx) return GP_EINVAL;
     GP_REQUIRE(ctx, X && y && thetas && lml, "null pointer");
     GP_REQUIRE(ctx, n >= 1 && d >= 1 && d <= 64 && ldx >= n && B >= 0 && max_sweeps >= 1, "bad dimensions");
@@ -835,11 +881,13 @@ gp_status gp_ep_lml_rbf_batched(gp_ctx *ctx, const double *X, int n, int d, int 
             }
             if (es == GP_ENOTPD) {
                 lml[b] = NAN;
+                if (grad) for (int q = 0; q < P; ++q) grad[(size_t)b * P + q] = NAN;
                 if (info) info[b] = h;
             } else if (es != GP_OK) {
                 st = es;
             } else if (st == GP_OK) {
                 st = gp_ep_lml(ep, strict, lml + b);
+                if (st == GP_OK && grad) st = ep_lml_grad_dev(ep, dX, d, thetas + (size_t)b * P, strict, grad + (size_t)b * P);
                 if (info) info[b] = 0;
             }
             if (sweeps) sweeps[b] = j;

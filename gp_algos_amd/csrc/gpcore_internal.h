@@ -6,6 +6,7 @@
 #include <cstring>
 #include <cstdlib>
 #include <cmath>
+#include <functional>
 #include <vector>
 
 #include "../../include/gpcore.h"
@@ -150,6 +151,11 @@ gp_status gpi_download_2d(gp_ctx *ctx, double *dst, int ldd, const double *src, 
 gp_status gpi_read_info(gp_ctx *ctx, int *info);
 gp_ctx *gpi_child_ctx(gp_ctx *ctx, int k);
 gp_status gpi_model_alpha(gp_model *m, double *dst);
+// L-BFGS (`history` pairs, at most max_iter iterations, NC batched backtracking steps per iteration, best-seen rule) maximising
+// F over the first nparams entries of theta: the driver behind gp_optimize_rbf and gp_ep_optimize_rbf
+gp_status gpi_lbfgs_maximize(gp_ctx *ctx, int P, int nparams, const double *theta0, int max_iter, int history, int NC,
+                             const std::function<gp_status(const double *, int, double *, double *, int *)> &evaluate,
+                             double *theta_out, double *f_out, int *iters_out, int *evals_out);
 void gpi_chol_blocked(gp_ctx *ctx, double *A, int np, int lda, double *dinv, int extra);
 void gpi_solve_rows_lower(gp_ctx *ctx, double *Vt, int mp, const double *L, int np, int ldl, const double *dinv, double *sumsq,
                           const double *tvec = nullptr, double *dots = nullptr);

@@ -194,6 +194,16 @@ gp_status gp_ep_predict(gp_ep *ep, const double *Ks, int m, int ldks, const doub
  * max_sweeps is reached; stop_eps < 0 runs exactly max_sweeps.  lml[B]; sweeps[B] and info[B] optional (info: 0, or the
  * failing pivot of I + S^1/2 K S^1/2 with lml = NaN).  The reference's mis-keyed result map is not replicated. */
 gp_status gp_ep_lml_rbf_batched(gp_ctx *ctx, const double *X, int n, int d, int ldx, const int32_t *y, const double *thetas, int B, double stop_eps, int max_sweeps, int strict, double *lml, int *sweeps, int *info);
+/* MarginalLikelihoodEvaluator.logLikelihood (gp/classification/MarginalLikelihoodEvaluator.scala:33-44) at B settings: the EP
+ * log marginal likelihood of gp_ep_lml_rbf_batched AND its gradient w.r.t. all d+2 hyper-parameters (:46-66; strict as in
+ * gp_ep_lml_grad_rbf), grad B x (d+2) row-major (NaN where info[b] != 0). */
+gp_status gp_ep_lml_grad_rbf_batched(gp_ctx *ctx, const double *X, int n, int d, int ldx, const int32_t *y, const double *thetas, int B, double stop_eps, int max_sweeps, int strict, double *lml, double *grad, int *sweeps, int *info);
+/* GradientHyperParamsOptimizer.optimizeHyperParams, gp/classification/HyperParamsOptimization.scala:31-55, with the
+ * BreezeLbfgsOptimizer it is wired with (optimization/Optimization.scala:30-63: L-BFGS, m = history, maxIter = max_iter, best-seen
+ * point): maximises the EP log marginal likelihood over all d+2 hyper-parameters starting at theta0.  Every objective evaluation is
+ * a full EP run (Gram, sweeps until AvgBasedStopCriterion(stop_eps) -- stop_eps < 0: exactly max_sweeps --, LML and gradient);
+ * the trial steps of a line search run concurrently.  theta_out[d+2], *lml_out = EP LML there.  Iterates are not Breeze's. */
+gp_status gp_ep_optimize_rbf(gp_ctx *ctx, const double *X, int n, int d, int ldx, const int32_t *y, const double *theta0, double stop_eps, int max_sweeps, int strict, int max_iter, int history, double *theta_out, double *lml_out, int *iters_out, int *evals_out);
 void gp_ep_destroy(gp_ep *ep);
 
 /* ---- batched small-n posteriors: GP-UCB and GP-UKF --------------------------------------------- */
