@@ -71,6 +71,12 @@ SIGNATURES = {
     "gp_ep_lml_grad_rbf_batched": (_i, [_vp, _dp, _i, _i, _i, C.POINTER(C.c_int32), _dp, _i, _d, _i, _i, _dp, _dp, _ip, _ip]),
     "gp_ep_optimize_rbf": (_i, [_vp, _dp, _i, _i, _i, C.POINTER(C.c_int32), _dp, _d, _i, _i, _i, _i, _dp, _dp, _ip, _ip]),
     "gp_ep_destroy": (None, [_vp]),
+    "gp_gram_co2": (_i, [_vp, _dp, _i, _dp, _dp, _i, _i]),
+    "gp_dgram_co2": (_i, [_vp, _dp, _i, _dp, _i, _dp, _i]),
+    "gp_cross_gram_co2": (_i, [_vp, _dp, _i, _dp, _i, _dp, _dp, _i]),
+    "gp_fit_co2": (_i, [_vp, _dp, _i, _dp, _dp, _d, C.POINTER(_vp), _ip]),
+    "gp_lml_grad_co2_batched": (_i, [_vp, _dp, _i, _dp, _dp, _i, _i, _d, _dp, _dp, _ip]),
+    "gp_optimize_co2": (_i, [_vp, _dp, _i, _dp, _dp, _i, _d, _i, _i, _dp, _dp, _ip, _ip]),
     "gp_small_fit": (_i, [_vp, _dp, _i, _i, _i, _dp, _i, _i, _dp, _d, _i, C.POINTER(_vp), _ip]),
     "gp_small_from_factors": (_i, [_vp, _dp, _i, _i, _i, _dp, _i, _dp, _i, _dp, _i, C.POINTER(_vp)]),
     "gp_small_destroy": (None, [_vp]),

@@ -145,6 +145,50 @@ class Context:
         self.check(self._lib.gp_inv_lower(self.h, L.dptr(Lm), n, max(n, 1), L.dptr(out), max(n, 1)))
         return out
 
+    # -- Co2Kernel (gp/regression/Co2Prediction.scala:29-137): 1-D inputs, 11 hyper-parameters -------------------------------
+    def gram_co2(self, x, theta, xs=None, pos=0):
+        """Gram (xs None; full symmetric) / cross-Gram (xs given: len(xs) x n) / derivative Gram (pos = 1..11) of the Co2Kernel."""
+        x, theta = L.f64(np.asarray(x, dtype=np.float64).reshape(-1)), L.f64(theta)
+        if theta.size != 11:
+            raise ValueError("Co2Kernel takes 11 hyper-parameters")
+        n = x.size
+        if xs is not None:
+            xs = L.f64(np.asarray(xs, dtype=np.float64).reshape(-1))
+            K = np.zeros((xs.size, n), order="F")
+            self.check(self._lib.gp_cross_gram_co2(self.h, L.dptr(xs), xs.size, L.dptr(x), n, L.dptr(theta), L.dptr(K), max(xs.size, 1)))
+            return K
+        K = np.zeros((n, n), order="F")
+        if pos:
+            self.check(self._lib.gp_dgram_co2(self.h, L.dptr(x), n, L.dptr(theta), int(pos), L.dptr(K), max(n, 1)))
+        else:
+            self.check(self._lib.gp_gram_co2(self.h, L.dptr(x), n, L.dptr(theta), L.dptr(K), max(n, 1), L.GP_FULL))
+        return K
+
+    def lml_grad_co2_batched(self, x, y, thetas, nparams=None, sigma_noise=None):
+        x, y = L.f64(np.asarray(x, dtype=np.float64).reshape(-1)), L.f64(y)
+        thetas = np.ascontiguousarray(np.atleast_2d(thetas), dtype=np.float64)
+        B, P = thetas.shape
+        if P != 11 or y.size != x.size:
+            raise ValueError("dimension mismatch")
+        nparams = P if nparams is None else int(nparams)
+        lml, grad, info = np.zeros(B), np.zeros((B, max(nparams, 1))), np.zeros(B, dtype=np.int32)
+        sn = float("nan") if sigma_noise is None else float(sigma_noise)
+        self.check(self._lib.gp_lml_grad_co2_batched(self.h, L.dptr(x), x.size, L.dptr(y), L.dptr(thetas), B, nparams, sn, L.dptr(lml), L.dptr(grad),
+                                                     info.ctypes.data_as(C.POINTER(C.c_int))))
+        return lml, grad[:, :nparams], info
+
+    def optimize_co2(self, x, y, theta0, nparams=11, sigma_noise=None, max_iter=20, history=4):
+        x, y = L.f64(np.asarray(x, dtype=np.float64).reshape(-1)), L.f64(y)
+        theta0 = np.ascontiguousarray(theta0, dtype=np.float64)
+        if theta0.size != 11 or y.size != x.size:
+            raise ValueError("dimension mismatch")
+        out, lml = np.zeros(11), np.zeros(1)
+        its, evs = C.c_int(0), C.c_int(0)
+        sn = float("nan") if sigma_noise is None else float(sigma_noise)
+        self.check(self._lib.gp_optimize_co2(self.h, L.dptr(x), x.size, L.dptr(y), L.dptr(theta0), int(nparams), sn, int(max_iter), int(history),
+                                             L.dptr(out), L.dptr(lml), C.byref(its), C.byref(evs)))
+        return out, float(lml[0]), its.value, evs.value
+
     def posterior_from_factor(self, X, theta, Lm, alpha, Xs, full_cov=False, want_v=False):
         """gp_posterior_from_factor (GpPredictor.computePosterior with the ARD-RBF kernel): (mean, var, cov|None, V|None)."""
         X, theta, Lm, alpha, Xs = L.f64(X), L.f64(theta), L.f64(Lm), L.f64(alpha), L.f64(Xs)
@@ -261,7 +305,7 @@ class Context:
 class RegressionModel:
     """(L, alpha, LML) of GpPredictor.preComputeComponents, resident on the GPU."""
 
-    def __init__(self, ctx, X=None, y=None, theta=None, sigma_noise=None, gram=None):
+    def __init__(self, ctx, X=None, y=None, theta=None, sigma_noise=None, gram=None, kernel="rbf"):
         self.ctx = ctx
         lib = ctx._lib
         h = C.c_void_p()
@@ -274,6 +318,14 @@ class RegressionModel:
             if y.size != self.n:
                 raise ValueError("Number of objects in training data matrix should be equal to targets vector length")
             st = lib.gp_fit_from_gram(ctx.h, L.dptr(K), self.n, self.n, L.dptr(y), C.byref(h), C.byref(info))
+        elif kernel == "co2":   # gp_fit_co2: Co2Kernel on 1-D inputs, the kernel is rebuilt on the device for predictions
+            x, theta = L.f64(np.asarray(X, dtype=np.float64).reshape(-1)), L.f64(theta)
+            self.n, self.d = x.size, 1
+            if y.size != self.n:
+                raise ValueError("Number of objects in training data matrix should be equal to targets vector length")
+            if theta.size != 11:
+                raise ValueError("Co2Kernel takes 11 hyper-parameters")
+            st = lib.gp_fit_co2(ctx.h, L.dptr(x), self.n, L.dptr(y), L.dptr(theta), sn, C.byref(h), C.byref(info))
         else:
             X, theta = L.f64(X), L.f64(theta)
             self.n, self.d = X.shape

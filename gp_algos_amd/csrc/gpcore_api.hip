@@ -375,6 +375,7 @@ void gpi_solve_rows_lower(gp_ctx *ctx, double *Vt, int mp, const double *L, int 
                           const double *tvec, double *dots) { solve_rows_lower(ctx, Vt, mp, L, np, ldl, dinv, sumsq, tvec, dots); }
 void gpi_inverse_transpose_lower(gp_ctx *ctx, double *T, const double *L, int np, int ldl, const double *dinv) { inverse_transpose_lower(ctx, T, L, np, ldl, dinv); }
 void gpi_back_solve_vec(gp_ctx *ctx, const double *L, int np, int ldl, const double *dinv, double *z, double *alpha) { back_solve_vec(ctx, L, np, ldl, dinv, z, alpha); }
+gp_status gpi_model_alloc(gp_ctx *ctx, int n, int d, bool has_x, gp_model **out) { return model_alloc(ctx, n, d, has_x, out); }
 // alpha of a fitted model (computed on demand) copied into a caller's device buffer of n doubles
 gp_status gpi_model_alpha(gp_model *m, double *dst) {
     ensure_alpha(m);
@@ -678,10 +679,11 @@ gp_status gp_model_refit_dev(gp_model *m, const double *theta, double sigma_nois
     gp_ctx *ctx = m->ctx;
     GP_REQUIRE(ctx, m->has_x && theta, "model has no training inputs (built from a Gram matrix)");
     GP_HIP(ctx, hipSetDevice(ctx->device));
-    m->theta.assign(theta, theta + m->d + 2);
+    m->theta.assign(theta, theta + (m->kind == 1 ? 11 : m->d + 2));
     m->sigma_noise = sigma_noise;
     gp_prof_begin(ctx, GP_PROF_GRAM);
-    gpk_gram_sym(ctx->stream, m->dX, m->n, m->d, m->n, theta, m->dL, m->ldl, 0, std::isnan(sigma_noise) ? 0.0 : sigma_noise);
+    if (m->kind == 1) gpk_co2_gram(ctx->stream, m->dX, m->n, m->dX, m->n, theta, 0, m->dL, m->ldl, 1, 0, std::isnan(sigma_noise) ? 0.0 : sigma_noise);
+    else gpk_gram_sym(ctx->stream, m->dX, m->n, m->d, m->n, theta, m->dL, m->ldl, 0, std::isnan(sigma_noise) ? 0.0 : sigma_noise);
     gp_prof_end(ctx, GP_PROF_GRAM, 8.0 * m->n * (m->n + 1.0) / 2.0 + 8.0 * m->n * m->d);
     model_factor(m);
     GP_LAUNCH_CHECK(ctx);
@@ -803,7 +805,8 @@ static gp_status predict_core(gp_model *mdl, const double *dXs, int m, int ldxs,
         GP_HIP(ctx, hipMemset2DAsync(Vt + m, (size_t)mp * 8, 0, (size_t)(mp - m) * 8, n, s));
     }
     gp_prof_begin(ctx, GP_PROF_GRAM);
-    gpk_gram_cross(s, dXs, m, ldxs, mdl->dX, n, n, mdl->d, mdl->theta.data(), Vt, mp);
+    if (mdl->kind == 1) gpk_co2_gram(s, dXs, m, mdl->dX, n, mdl->theta.data(), 0, Vt, mp, 0, 1, 0.0);
+    else gpk_gram_cross(s, dXs, m, ldxs, mdl->dX, n, n, mdl->d, mdl->theta.data(), Vt, mp);
     gp_prof_end(ctx, GP_PROF_GRAM, 8.0 * m * (double)n + 8.0 * (m + n) * mdl->d);
     // sumsq and the mean accumulate inside the row-panel solves: var = kss - |v|^2, mean = v . (L^-1 y)  (= K* alpha)
     double *dots = partial;
@@ -827,8 +830,8 @@ static gp_status predict_core(gp_model *mdl, const double *dXs, int m, int ldxs,
     solve_rows_lower(ctx, Vt, mp, mdl->dL, np, mdl->ldl, mdl->ddinv, sumsq, mdl->dtmp, dots, Lw);
     GP_HIP(ctx, hipMemcpyAsync(dmean, dots, sizeof(double) * m, hipMemcpyDeviceToDevice, s));
     if (dvar) {
-        const double sf = mdl->theta[0], sn = mdl->theta[mdl->d + 1];
-        gpk_var_finish(s, dvar, sumsq, m, sf * sf + sn * sn);
+        const double sf = mdl->theta[0], sn = mdl->kind == 1 ? 0.0 : mdl->theta[mdl->d + 1];
+        gpk_var_finish(s, dvar, sumsq, m, mdl->kind == 1 ? gpk_co2_kss(mdl->theta.data()) : sf * sf + sn * sn);
     }
     if (vt_out) *vt_out = Vt;
     if (mp_out) *mp_out = mp;
@@ -878,7 +881,8 @@ gp_status gp_predict(gp_model *mdl, const double *Xs, int m, int ldxs, double *m
         // (sn^2 on its diagonal) minus Vt Vt^T on the MFMA syrk, then mirrored on the host copy-out.
         double *dC;
         GP_TRY(ws_get(ctx, WS_D, sizeof(double) * (size_t)mp * mp, &dC));
-        gpk_gram_sym(ctx->stream, dXs, m, d, m, mdl->theta.data(), dC, mp, 1, 0.0);
+        if (mdl->kind == 1) gpk_co2_gram(ctx->stream, dXs, m, dXs, m, mdl->theta.data(), 0, dC, mp, 1, 1, 0.0);
+        else gpk_gram_sym(ctx->stream, dXs, m, d, m, mdl->theta.data(), dC, mp, 1, 0.0);
         gpk_pad_identity(ctx->stream, dC, m, mp, mp);
         gp_prof_begin(ctx, GP_PROF_SYRK);
         gpk_gemm_nt(ctx->stream, mp, mp, mdl->np, -1.0, Vt, mp, Vt, mp, 1.0, dC, mp, 1);

@@ -53,6 +53,7 @@ struct gp_model {
     int n = 0, d = 0, np = 0;        // np = padded n
     int ldl = 0;                     // leading dimension of dL = np + GP_NB: one extra row strip carries y^T through the factorisation
     bool has_x = false;              // false for gp_fit_from_gram
+    int kind = 0;                    // kernel the model rebuilds Gram matrices with: 0 = ARD-RBF (theta = d + 2), 1 = Co2Kernel (d = 1, theta = 11)
     double *dX = nullptr;            // n x d, ld = n
     double *dy = nullptr;            // np
     double *dL = nullptr;            // (np + GP_NB) x np, ld = ldl; row np holds y^T -> (L^-1 y)^T
@@ -103,6 +104,11 @@ void gpk_gemm_nt_rowred(hipStream_t s, int M, int N, int K, const double *A, int
 void gpk_gram_sym(hipStream_t s, const double *X, int n, int d, int ldx, const double *theta, double *K, int ldk, int full, double extra_diag);
 void gpk_dgram_sym(hipStream_t s, const double *X, int n, int d, int ldx, const double *theta, int pos, double *D, int ldd);
 void gpk_gram_cross(hipStream_t s, const double *Xs, int m, int ldxs, const double *X, int n, int ldx, int d, const double *theta, double *Ks, int ldks);
+// Co2Kernel (gp/regression/Co2Prediction.scala:29-137), 1-D inputs, theta = hp1..hp11 on the host; pos = 0: kernel, 1..11: derivative
+void gpk_co2_gram(hipStream_t s, const double *xr, int nr, const double *xc, int nc, const double *theta, int pos, double *K, int ldk, int sym,
+                  int full, double extra);
+void gpk_co2_trace(hipStream_t s, int n, const double *alpha, const double *Kinv, int ldk, const double *D, int ldd, double *partial, double *out);
+double gpk_co2_kss(const double *theta);
 // set rows/cols [n, np) of the np x np matrix to identity (pad block) and zero the cross blocks.
 void gpk_pad_identity(hipStream_t s, double *A, int n, int np, int lda);
 void gpk_zero_upper(hipStream_t s, double *A, int n, int lda);
@@ -151,6 +157,7 @@ gp_status gpi_download_2d(gp_ctx *ctx, double *dst, int ldd, const double *src, 
 gp_status gpi_read_info(gp_ctx *ctx, int *info);
 gp_ctx *gpi_child_ctx(gp_ctx *ctx, int k);
 gp_status gpi_model_alpha(gp_model *m, double *dst);
+gp_status gpi_model_alloc(gp_ctx *ctx, int n, int d, bool has_x, gp_model **out);
 // L-BFGS (`history` pairs, at most max_iter iterations, NC batched backtracking steps per iteration, best-seen rule) maximising
 // F over the first nparams entries of theta: the driver behind gp_optimize_rbf and gp_ep_optimize_rbf
 gp_status gpi_lbfgs_maximize(gp_ctx *ctx, int P, int nparams, const double *theta0, int max_iter, int history, int NC,

@@ -15,6 +15,7 @@ from ...core import RegressionModel
 from ...optimization.optimization import BreezeLbfgsOptimizer
 from ...utils import matrix_utils
 from ...utils.kernel_requisites import GaussianRbfKernel
+from .co2_prediction import Co2Kernel
 from ...utils.stats_utils import GaussianDistribution
 
 
@@ -50,6 +51,10 @@ class GpPredictor:
         ctx = default_context()
         if isinstance(kf, GaussianRbfKernel):
             return kf, RegressionModel(ctx, X, y, kf.rbfParams.toDenseVector(), sigma_noise=sigmaNoise)
+        if isinstance(kf, Co2Kernel):            # a composite kernel with a device path of its own (gp_fit_co2)
+            if X.shape[1] != 1:
+                raise ValueError("requirement failed: This kernel is applicable only for 1D objects")
+            return kf, RegressionModel(ctx, X[:, 0], y, kf.hyperParams.toDenseVector(), sigma_noise=sigmaNoise, kernel="co2")
         K = matrix_utils.buildKernelMatrix(kf, X)
         if sigmaNoise is not None:
             K = K + np.eye(X.shape[0]) * sigmaNoise   # un-squared, :116
@@ -76,7 +81,7 @@ class GpPredictor:
         kf, mdl = self._fit(input.trainingData, hyperParams, input.sigmaNoise, input.targets)
         try:
             Xs = np.asfortranarray(np.asarray(input.testData, dtype=np.float64))
-            if isinstance(kf, GaussianRbfKernel):
+            if isinstance(kf, (GaussianRbfKernel, Co2Kernel)):
                 mean, _, cov = mdl.predict(Xs, full_cov=True)
             else:
                 mean, cov = self._posterior_from_host_gram(kf, input.trainingData, Xs, mdl)
@@ -113,11 +118,15 @@ class GpPredictor:
 
     def logLikelihoodWithDerivatives(self, input, hyperParams, optimizedParamsNum):   # :60-80
         kf = self.kernelFunc.changeHyperParams(hyperParams.toDenseVector())
-        if not isinstance(kf, GaussianRbfKernel):
-            raise NotImplementedError("device LML gradient is implemented for GaussianRbfKernel")
         X = np.asfortranarray(np.asarray(input.trainingData, dtype=np.float64))
-        lml, grad, info = default_context().lml_grad_batched(X, input.targets, kf.rbfParams.toDenseVector()[None, :],
-                                                             nparams=optimizedParamsNum, sigma_noise=input.sigmaNoise)
+        if isinstance(kf, Co2Kernel):
+            lml, grad, info = default_context().lml_grad_co2_batched(X[:, 0], input.targets, kf.hyperParams.toDenseVector()[None, :],
+                                                                     nparams=optimizedParamsNum, sigma_noise=input.sigmaNoise)
+        elif isinstance(kf, GaussianRbfKernel):
+            lml, grad, info = default_context().lml_grad_batched(X, input.targets, kf.rbfParams.toDenseVector()[None, :],
+                                                                 nparams=optimizedParamsNum, sigma_noise=input.sigmaNoise)
+        else:
+            raise NotImplementedError("device LML gradient is implemented for GaussianRbfKernel and Co2Kernel")
         if info[0]:
             from ..._lib import NotPositiveDefinite
             raise NotPositiveDefinite(2, "matrix not positive definite at pivot %d" % info[0], int(info[0]))
@@ -125,6 +134,11 @@ class GpPredictor:
 
     def obtainOptimalHyperParams(self, trainingData, sigmaNoise, targets, optimizeNoise):   # :126-142
         full = self.kernelFunc.hyperParams.toDenseVector()
+        if isinstance(self.kernelFunc, Co2Kernel):
+            x = np.asarray(trainingData, dtype=np.float64).reshape(-1)
+            best, _, _, _ = default_context().optimize_co2(x, targets, full, nparams=11 if optimizeNoise else 10, sigma_noise=sigmaNoise,
+                                                           max_iter=20, history=4)
+            return self.kernelFunc.hyperParams.fromDenseVector(best)
         if optimizeNoise and isinstance(self.kernelFunc, GaussianRbfKernel):
             # native L-BFGS (gp_optimize_rbf): same objective, memory (m = 4), iteration cap (20) and best-seen rule as
             # BreezeLbfgsOptimizer; training data stay on the GPU and each line search is one lockstep batch

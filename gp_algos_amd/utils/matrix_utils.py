@@ -24,6 +24,14 @@ def buildKernelMatrix(kernelFun, input1, input2=None):
         if input2 is None:
             return ctx.gram_rbf(X1, theta, full=True)
         return ctx.cross_gram_rbf(X1, _mat(input2), theta)
+    from ..gp.regression.co2_prediction import Co2Kernel
+    if isinstance(kernelFun, Co2Kernel):          # a user KernelFunc of the reference that also has a device path (gp_*_co2)
+        if X1.shape[1] != 1:
+            raise ValueError("requirement failed: This kernel is applicable only for 1D objects")
+        theta = kernelFun.hyperParams.toDenseVector()
+        if input2 is None:
+            return default_context().gram_co2(X1[:, 0], theta)
+        return default_context().gram_co2(_mat(input2)[:, 0], theta, xs=X1[:, 0])
     if input2 is None:
         return buildMatrixWithFunc(X1)(lambda a, b, same: kernelFun.apply(a, b, same))
     return buildMatrixWithFunc(lambda a, b: kernelFun.apply(a, b, False), X1, _mat(input2))
@@ -40,6 +48,10 @@ def buildMatrixWithFunc(*args):
             if tag is not None:      # f = GaussianRbfKernel.derAfterHyperParam(p): gp_dgram_rbf builds dK/dtheta_p on the device
                 kernel, pos = tag
                 return default_context().dgram_rbf(data, kernel.rbfParams.toDenseVector(), pos)
+            tag = getattr(f, "_gpcore_co2", None)
+            if tag is not None:      # f = Co2Kernel.derAfterHyperParam(p): gp_dgram_co2
+                kernel, pos = tag
+                return default_context().gram_co2(data[:, 0], kernel.hyperParams.toDenseVector(), pos=pos)
             n = data.shape[0]
             out = np.zeros((n, n), order="F")
             for i in range(n):

@@ -206,6 +206,22 @@ gp_status gp_ep_lml_grad_rbf_batched(gp_ctx *ctx, const double *X, int n, int d,
 gp_status gp_ep_optimize_rbf(gp_ctx *ctx, const double *X, int n, int d, int ldx, const int32_t *y, const double *theta0, double stop_eps, int max_sweeps, int strict, int max_iter, int history, double *theta_out, double *lml_out, int *iters_out, int *evals_out);
 void gp_ep_destroy(gp_ep *ep);
 
+/* ---- a composite user kernel on the device: Co2Kernel --------------------------------------------- */
+/* gp/regression/Co2Prediction.scala:29-137: k = k1 (squared exponential) + k2 (decaying periodic) + k3 (rational quadratic) +
+ * k4 (squared exponential + hp11^2 on the diagonal), 11 hyper-parameters hp1..hp11 in the order of Co2HyperParams (1-based
+ * getAtPosition :24), ONE-dimensional inputs x[n].  Same contracts as the *_rbf entry points. */
+gp_status gp_gram_co2(gp_ctx *ctx, const double *x, int n, const double *theta, double *K, int ldk, int uplo);
+/* buildMatrixWithFunc(x)(Co2Kernel.derAfterHyperParam(pos)), :69-137; pos 1..11, else GP_ERANGE (MatchError) */
+gp_status gp_dgram_co2(gp_ctx *ctx, const double *x, int n, const double *theta, int pos, double *D, int ldd);
+gp_status gp_cross_gram_co2(gp_ctx *ctx, const double *xs, int m, const double *x, int n, const double *theta, double *Ks, int ldks);
+/* GpPredictor(co2Kernel).preComputeComponents: the returned model works with gp_model_get, gp_predict (Xs = xs, ldxs >= m, the
+ * kernel rebuilt on the device) and gp_model_refit_dev (theta = 11 values). */
+gp_status gp_fit_co2(gp_ctx *ctx, const double *x, int n, const double *y, const double *theta, double sigma_noise, gp_model **out, int *info);
+/* GpPredictor.logLikelihoodWithDerivatives (:60-80) with Co2Kernel at B settings (thetas B x 11 row-major); grad B x nparams. */
+gp_status gp_lml_grad_co2_batched(gp_ctx *ctx, const double *x, int n, const double *y, const double *thetas, int B, int nparams, double sigma_noise, double *lml, double *grad, int *info);
+/* GpPredictor.obtainOptimalHyperParams (:126-142) with Co2Kernel: L-BFGS (m = history, maxIter = max_iter, best-seen point). */
+gp_status gp_optimize_co2(gp_ctx *ctx, const double *x, int n, const double *y, const double *theta0, int nparams, double sigma_noise, int max_iter, int history, double *theta_out, double *lml_out, int *iters_out, int *evals_out);
+
 /* ---- batched small-n posteriors: GP-UCB and GP-UKF --------------------------------------------- */
 /* The heaviest callers of GpPredictor.computePosterior (gp/regression/GpPredictor.scala:45-58) ask for ONE test point per call
  * against a few hundred training points: GPOptimizer.maximizeUCB (gp/optimization/GPOptimizer.scala:82-109) inside L-BFGS, and

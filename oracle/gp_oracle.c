@@ -406,6 +406,69 @@ int orc_ucb(const double *X, int n, int d, int ldx, const double *theta, const d
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* gp/regression/Co2Prediction.scala:29-137  Co2Kernel: apply (:39-56) and derAfterHyperParam   */
+/* (:69-137) on 1-D inputs, hp = hp1..hp11 (Co2HyperParams.getAtPosition is 1-based, :24).      */
+/* ------------------------------------------------------------------------------------------ */
+double orc_co2_kernel(double x1, double x2, int same, const double *hp) {
+    double hp1 = hp[0], hp2 = hp[1], hp3 = hp[2], hp4 = hp[3], hp5 = hp[4], hp6 = hp[5], hp7 = hp[6], hp8 = hp[7], hp9 = hp[8],
+           hp10 = hp[9], hp11 = hp[10];
+    double xDiff = x1 - x2, xDiffSq = (x1 - x2) * (x1 - x2);
+    double k1Val = hp1 * hp1 * exp(-xDiffSq / (2 * hp2 * hp2));
+    double sinVal = sin(M_PI * xDiff);
+    double k2Val = hp3 * hp3 * exp((-xDiffSq / (2 * hp4 * hp4)) - 2 * sinVal * sinVal / (hp5 * hp5));
+    double k3Pow1 = 1 + xDiffSq / (2 * hp8 * hp7 * hp7);
+    double k3Val = hp6 * hp6 * pow(k3Pow1, -hp8);
+    double k4Val = hp9 * hp9 * exp(-xDiffSq / (2 * hp10 * hp10));
+    double indNoise = same ? hp11 * hp11 : 0.0;
+    return k1Val + k2Val + k3Val + k4Val + indNoise;
+}
+/* num is 1-BASED; returns ORC_EINVAL past 11 where the Scala match throws MatchError */
+int orc_co2_der(double x1, double x2, int same, int num, const double *hp, double *out) {
+    double hp1 = hp[0], hp2 = hp[1], hp3 = hp[2], hp4 = hp[3], hp5 = hp[4], hp6 = hp[5], hp7 = hp[6], hp8 = hp[7], hp9 = hp[8],
+           hp10 = hp[9], hp11 = hp[10];
+    double xDiff = x1 - x2, sqDiff = (x1 - x2) * (x1 - x2);
+    if (num < 1 || num > 11) return ORC_EINVAL;
+    if (num < 3) {
+        *out = (num == 1) ? 2 * hp1 * exp(-sqDiff / (2 * hp2 * hp2)) : hp1 * hp1 * exp(-sqDiff / (2 * hp2 * hp2)) * sqDiff * pow(hp2, -3.0);
+    } else if (num < 6) {
+        double sinVal = sin(M_PI * xDiff);
+        double k2Val = hp3 * hp3 * exp(-sqDiff / (2 * hp4 * hp4) - 2 * sinVal * sinVal / (hp5 * hp5));
+        *out = (num == 3) ? 2 * k2Val / hp3 : (num == 4) ? k2Val * sqDiff * pow(hp4, -3.0) : k2Val * 4 * sinVal * sinVal * pow(hp5, -3.0);
+    } else if (num < 9) {
+        double k3Pow1 = 1 + sqDiff / (2 * hp8 * hp7 * hp7);
+        if (num == 6) *out = 2 * hp6 * pow(k3Pow1, -hp8);
+        else if (num == 7) *out = hp6 * hp6 * pow(k3Pow1, -hp8 - 1) * sqDiff * pow(hp7, -3.0);
+        else {
+            double firstTerm = exp(-hp8 * log(k3Pow1));
+            double secondTerm = -log(k3Pow1) + (hp8 * sqDiff / (2 * hp7 * hp7 * hp8 * hp8 * k3Pow1));
+            *out = hp6 * hp6 * firstTerm * secondTerm;
+        }
+    } else {
+        double k4Val = hp9 * hp9 * exp(-sqDiff / (2 * hp10 * hp10));
+        *out = (num == 9) ? 2 * k4Val / hp9 : (num == 10) ? k4Val * sqDiff * pow(hp10, -3.0) : (same ? 2 * hp11 : 0.0);
+    }
+    return ORC_OK;
+}
+/* MatrixUtils.buildKernelMatrix / buildMatrixWithFunc with the kernel above: pos = 0 the kernel, 1..11 a derivative; symmetric
+ * (xs == NULL: lower evaluated with the i == j flag, mirrored) or cross (never the noise flag) */
+int orc_co2_gram(const double *x, int n, const double *xs, int m, const double *hp, int pos, double *K, int ldk) {
+    if (!xs) {
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j <= i; ++j) {
+                double v;
+                if (pos) { int rc = orc_co2_der(x[i], x[j], i == j, pos, hp, &v); if (rc) return rc; }
+                else v = orc_co2_kernel(x[i], x[j], i == j, hp);
+                EL(K, ldk, i, j) = v;
+                EL(K, ldk, j, i) = v;
+            }
+        return ORC_OK;
+    }
+    for (int i = 0; i < m; ++i)
+        for (int j = 0; j < n; ++j) EL(K, ldk, i, j) = orc_co2_kernel(xs[i], x[j], 0, hp);
+    return ORC_OK;
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* EpParameterEstimator.scala:98-109 marginalMoments                                            */
 /* ------------------------------------------------------------------------------------------ */
 static void marginal_moments(double cav_mi, double cav_sigma, int target, double *mi_hat, double *sigma_hat) {

@@ -40,6 +40,8 @@ def lib():
         _lib.orc_lml.restype = _d
         _lib.orc_ep_lml.restype = _d
         _lib.orc_avg_between_site_params.restype = _d
+        _lib.orc_co2_kernel.restype = _d
+        _lib.orc_co2_kernel.argtypes = [_d, _d, _i, C.POINTER(C.c_double)]
     return _lib
 
 
@@ -219,6 +221,28 @@ def ucb(X, theta, L, alpha, x, kappa):
     rc = lib().orc_ucb(_p(X), _i(n), _i(d), _ld(X), _p(theta), _p(L), _ld(L), _p(alpha), _p(x), _d(float(kappa)), C.byref(val), _p(grad))
     assert rc == 0
     return val.value, grad
+
+
+def co2_kernel(x1, x2, same, hp):
+    """Co2Kernel.apply, gp/regression/Co2Prediction.scala:39-56."""
+    hp = _f(hp)
+    return lib().orc_co2_kernel(_d(float(x1)), _d(float(x2)), _i(1 if same else 0), _p(hp))
+
+
+def co2_gram(x, hp, xs=None, pos=0):
+    """Gram (xs None: symmetric with the noise flag, mirrored) / cross-Gram / derivative Gram (pos = 1..11) of the Co2Kernel."""
+    x, hp = _f(np.asarray(x, dtype=np.float64).reshape(-1)), _f(hp)
+    n = x.size
+    if xs is None:
+        K = np.zeros((n, n), order="F")
+        rc = lib().orc_co2_gram(_p(x), _i(n), None, _i(0), _p(hp), _i(pos), _p(K), _i(n))
+    else:
+        xs = _f(np.asarray(xs, dtype=np.float64).reshape(-1))
+        K = np.zeros((xs.size, n), order="F")
+        rc = lib().orc_co2_gram(_p(x), _i(n), _p(xs), _i(xs.size), _p(hp), _i(pos), _p(K), _i(xs.size))
+    if rc:
+        raise IndexError("hyper-parameter position %d outside 1..11 (MatchError)" % pos)
+    return K
 
 
 def marginal_moments(cav_mi, cav_sigma, target):
