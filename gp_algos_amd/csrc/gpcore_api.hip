@@ -104,7 +104,11 @@ void chol_blocked(gp_ctx *ctx, double *A, int np, int lda, double *dinv, int ext
     bdiag.s0 = strideA, bdiag.s1 = strideDinv;
     btrsm.s0 = strideA, btrsm.s1 = strideA, btrsm.s2 = strideDinv;
     bgemm.s0 = bgemm.s1 = bgemm.s2 = strideA;
-    const bool lookahead = ctx->lookahead && count == 1;
+    // Look-ahead (far part of the outer update on the CU-masked side stream, under the next panel's chain): -1 = by size.
+    // Measured with the side stream's reserved CUs spread over the XCDs (gp_ctx_create): n = 8192 fit 7.89 -> 7.40 ms, n = 4096
+    // 2.79 -> 2.96 ms (the chain kernels slow down 2-4x while a full-chip GEMM runs beside them, so short factorisations lose),
+    // n = 32768 198 -> 196..203 ms; the EP refactorisation (4096 rows of V riding along) 96.6 -> 99.5 sweeps/s.
+    const bool lookahead = count == 1 && (ctx->lookahead > 0 || (ctx->lookahead < 0 && rows >= 6144 && np < 16384));
     bool side_busy = false;
     // outer panel width: 512 (K = 512 trailing updates); 1024 measured 3 % faster at n = 32768 (205 -> 198.5 ms), equal at 8192
     const int outer_env = gp_env_blocks("GPCORE_OUTER");
@@ -425,8 +429,8 @@ gp_status gp_ctx_create(int device, void *stream, gp_ctx **out) {
         // Side stream for the far trailing update of the Cholesky.  It is CU-masked to leave a few CUs free of its
         // long-running GEMM workgroups: the single-workgroup diagonal-block kernel on the main stream needs ~150 KB
         // of LDS, i.e. a whole CU, and otherwise waits hundreds of microseconds for two GEMM workgroups on one CU
-        // to retire together.  GPCORE_RESERVED_CUS (default 8, 0 = no mask) sets how many CUs stay reserved.
-        int reserved = 8;
+        // to retire together.  GPCORE_RESERVED_CUS (default 32 = 4 per XCD, 0 = no mask) sets how many CUs stay reserved.
+        int reserved = 32;
         if (const char *rc = getenv("GPCORE_RESERVED_CUS")) reserved = atoi(rc);
         hipError_t em = hipErrorInvalidValue;
         if (reserved > 0 && ctx->num_cu >= 64) {
@@ -444,7 +448,7 @@ gp_status gp_ctx_create(int device, void *stream, gp_ctx **out) {
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_a, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_b, hipEventDisableTiming);
-    if (const char *la = getenv("GPCORE_LOOKAHEAD")) ctx->lookahead = atoi(la) != 0;
+    if (const char *la = getenv("GPCORE_LOOKAHEAD")) ctx->lookahead = atoi(la) != 0 ? 1 : 0;
     if (e == hipSuccess) e = hipMalloc(&ctx->d_scalars, sizeof(double) * 256);
     if (e == hipSuccess) e = hipMalloc(&ctx->d_info, sizeof(int) * 4);
     if (e == hipSuccess) e = hipMemset(ctx->d_info, 0, sizeof(int) * 4);

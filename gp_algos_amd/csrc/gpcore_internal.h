@@ -40,8 +40,7 @@ struct gp_ctx {
     int prof_which = GP_PROF_OFF;
     gp_prof_slot prof[GP_PROF_NCLASSES];
     int num_cu = 256;
-    bool lookahead = false;       // GPCORE_LOOKAHEAD=1: run the far trailing update on the side stream, overlapping the next panel.
-                                  // Measured slower at n = 8192..32768 (the 150 KB-LDS diagonal kernel starves behind the GEMM), so off.
+    int lookahead = -1;           // far trailing update of the Cholesky on the side stream: 1 on, 0 off, -1 by size (chol_blocked); GPCORE_LOOKAHEAD
     char err[512] = {0};
     // scratch reused across calls
     double *d_scalars = nullptr;  // small device scratch (256 doubles)
