@@ -83,6 +83,25 @@ def cpu_baseline(p, L_host, alpha_host, m_total, budget_pts=256):
                        % ("/".join(map(str, sizes)), n, k, m_total, n, m_total, m_total)), mean, var, k
 
 
+def _cholesky_block(n, t_fit, t_fit_serial, o_k, o_ms, o_work, p_k, p_ms, p_work):
+    """Cholesky figures of the bench line.  The trailing update is reported over ALL update launches -- the K = 512 outer updates
+    and the K = 128 in-panel updates -- with SURVEY.md 8(d)'s exact count  sum_k nb r_k (r_k + 1),  r_k = n - (k + 1) nb,  nb = 128
+    (the kernels' own tile count, which includes the strict upper half of the diagonal tiles, is given beside it)."""
+    nb = 128
+    exact = float(sum(nb * (n - (k + 1) * nb) * (n - (k + 1) * nb + 1) for k in range(n // nb - 1)))
+    upd_s = (o_ms + p_ms) * 1e-3
+    out = {"fit_ms": t_fit * 1e3, "total_tflops": (n ** 3 / 3.0) / t_fit / 1e12,
+           "fit_ms_lookahead_off": t_fit_serial * 1e3, "panel_width_inner": nb, "outer_update_K": 512,
+           "trailing_update_tflops": exact / upd_s / 1e12 if upd_s > 0 else 0.0,
+           "trailing_update_frac_of_peak": exact / upd_s / 1e12 / PEAK_FP64_MFMA_TFLOPS if upd_s > 0 else 0.0,
+           "trailing_update_flops_exact": exact, "trailing_update_flops_tiles": o_work + p_work,
+           "trailing_update_ms": (o_ms + p_ms), "trailing_update_launches": o_k + p_k,
+           "outer_update_tflops_tiles": o_work / (o_ms * 1e-3) / 1e12 if o_ms > 0 else 0.0, "outer_update_launches": o_k,
+           "in_panel_update_tflops_tiles": p_work / (p_ms * 1e-3) / 1e12 if p_ms > 0 else 0.0, "in_panel_update_launches": p_k,
+           "trailing_update_measured": "one refit with the look-ahead switched off (gp_ctx_set_lookahead 0), HIP events per launch"}
+    return out
+
+
 def _roofline_from_profile(ctx, L, classes, names):
     """The kernel class that took the most stream time during the timed steps (HIP events recorded by the library around every
     launch of that class, on the stream the launch went to): achieved = algorithmic flops of its launches / their summed time."""
@@ -289,7 +308,7 @@ def run_secondary(args):
     gdist.barrier()
 
 
-PMC_SUMMARY = "r01_e_pmc_c2_summary.json"
+PMC_SUMMARY = "r02_b_pmc_c2_summary.json"
 DOMINANT_KERNEL = "gemm_fused_kernel<0,0,1,8>"
 
 
@@ -447,6 +466,18 @@ def main():
     ctx.sync()
     t_pred = time.perf_counter() - t1
     ctx.check(lib.gp_model_status(h, C.byref(info)), info.value)
+    # The trailing-update kernels by themselves: one refit with the look-ahead off (overlapping launches would each be timed
+    # with the other running beside them), HIP events around every launch of the two classes
+    ctx.check(lib.gp_ctx_set_lookahead(ctx.h, 0))
+    ctx.profile((1 << L.GP_PROF_SYRK) | (1 << L.GP_PROF_PANEL_UPD))
+    t1 = time.perf_counter()
+    ctx.check(lib.gp_model_refit_dev(h, L.dptr(theta), nan))
+    ctx.sync()
+    t_fit_serial = time.perf_counter() - t1
+    ctx.profile(0)
+    ctx.check(lib.gp_ctx_set_lookahead(ctx.h, -1))
+    o_k, o_ms, o_work = ctx.profile_read(L.GP_PROF_SYRK)
+    p_k, p_ms, p_work = ctx.profile_read(L.GP_PROF_PANEL_UPD)
 
     out = None
     if rank == 0:
@@ -488,9 +519,7 @@ def main():
                          "algorithmic_bytes_per_launch": 8.0 * (m * ((n + 128) / 2.0) + 128 * ((n + 128) / 2.0) + m * 128),
                          "launches": g_k, "avg_launch_us": g_ms / max(g_k, 1) * 1e3,
                          "flops_per_launch_avg": g_work / max(g_k, 1)},
-            "cholesky": {"fit_ms": t_fit * 1e3, "total_tflops": (n ** 3 / 3.0) / t_fit / 1e12,
-                         "trailing_update_tflops": syrk_tflops, "trailing_update_frac_of_peak": syrk_tflops / PEAK_FP64_MFMA_TFLOPS,
-                         "trailing_update_launches": s_k, "panel_width_inner": 128, "trailing_update_K": 512},
+            "cholesky": _cholesky_block(n, t_fit, t_fit_serial, o_k, o_ms, o_work, p_k, p_ms, p_work),
             "gram": {"GBps": r_work / (r_ms * 1e-3) / 1e9 if r_ms > 0 else 0.0, "frac_of_hbm_peak": (r_work / (r_ms * 1e-3) / 1e9) / PEAK_HBM_GBS if r_ms > 0 else 0.0},
             "predict_only_points_per_s": m / t_pred, "predict_ms": t_pred * 1e3,
             "mfma_f64_probe_tflops": probe,

@@ -83,6 +83,22 @@ double trapezoid_flops(int M, int N, int K) {  // lower-trapezoid tiles (bi >= b
 }
 double syrk_flops(int r, int K) { return trapezoid_flops(r, r, K); }
 
+bool small_panel_update() {   // GPCORE_PANEL_SMALL=0: the general 128 x 128-tile kernel for the in-panel updates too
+    const char *e = getenv("GPCORE_PANEL_SMALL");
+    return !e || atoi(e) != 0;
+}
+
+double small_update_tiles() {   // outer updates with fewer 128 x 128 tiles than this use the 64 x 64 kernel (GPCORE_SMALL_UPDATE_TILES)
+    const char *e = getenv("GPCORE_SMALL_UPDATE_TILES");
+    return e ? atof(e) : 600.0;   // measured at 0 / 150 / 300 / 600 / 1200: n = 8192 fit 7.04 / 6.65 / 6.64 / 6.63 / 6.72 ms
+}
+
+// C (M x N, rectangular) -= A (M x K) B (N x K)^T for a SINGLE problem: launches with few 128 x 128 tiles go to the 64 x 64 kernel
+void gemm_sub_single(hipStream_t s, int M, int N, int K, const double *A, int lda, const double *B, int ldb, double *C, int ldc) {
+    if ((double)(M / GP_NB) * (N / GP_NB) < small_update_tiles() && small_panel_update()) gpk_gemm_k128_sub(s, M, N, A, lda, B, ldb, C, ldc, 0, K);
+    else gpk_gemm_nt(s, M, N, K, -1.0, A, lda, B, ldb, 1.0, C, ldc, 0);
+}
+
 // Two-level blocked right-looking Cholesky of the padded np x np matrix A (lower):
 //   inner (nb = 128), confined to one outer panel of GP_OUTER = 512 columns:
 //       potrf_diag128(Akk) -> Lkk + 16x16 tile inverses;  A21 <- A21 Lkk^-T (MFMA trsm panel, all rows below);
@@ -130,7 +146,10 @@ void chol_blocked(gp_ctx *ctx, double *A, int np, int lda, double *dinv, int ext
             const int wc = K0 + wcols - (k0 + GP_NB);
             if (wc > 0) {
                 gp_prof_begin(ctx, GP_PROF_PANEL_UPD);
-                gpk_gemm_nt(s, r, wc, GP_NB, -1.0, A21, lda, A21, lda, 1.0, A21 + (size_t)GP_NB * lda, lda, 1, 0, bgemm);
+                // a single factorisation: quarter-size tiles (the launch is bound by the latency of one tile, not by throughput);
+                // a lockstep batch fills the chip with the general 128 x 128 kernel
+                if (count == 1 && small_panel_update()) gpk_gemm_k128_sub(s, r, wc, A21, lda, A21, lda, A21 + (size_t)GP_NB * lda, lda, 1);
+                else gpk_gemm_nt(s, r, wc, GP_NB, -1.0, A21, lda, A21, lda, 1.0, A21 + (size_t)GP_NB * lda, lda, 1, 0, bgemm);
                 gp_prof_end(ctx, GP_PROF_PANEL_UPD, count * trapezoid_flops(r, wc, GP_NB));
             }
         }
@@ -152,7 +171,12 @@ void chol_blocked(gp_ctx *ctx, double *A, int np, int lda, double *dinv, int ext
             side_busy = true;
         }
         gp_prof_begin(ctx, GP_PROF_SYRK);
-        gpk_gemm_nt(s, rows - c1, nnext, wcols, -1.0, P, lda, P, lda, 1.0, A + (size_t)c1 + (size_t)c1 * lda, lda, 1, 0, bgemm);
+        // the last outer updates of a single factorisation have fewer 128 x 128 tiles than the chip has slots: quarter-size tiles
+        const double tiles128 = trapezoid_flops(rows - c1, nnext, wcols) / (2.0 * GP_NB * GP_NB * wcols);
+        if (count == 1 && tiles128 < small_update_tiles() && small_panel_update())
+            gpk_gemm_k128_sub(s, rows - c1, nnext, P, lda, P, lda, A + (size_t)c1 + (size_t)c1 * lda, lda, 1, wcols);
+        else
+            gpk_gemm_nt(s, rows - c1, nnext, wcols, -1.0, P, lda, P, lda, 1.0, A + (size_t)c1 + (size_t)c1 * lda, lda, 1, 0, bgemm);
         gp_prof_end(ctx, GP_PROF_SYRK, count * trapezoid_flops(rows - c1, nnext, wcols));
     }
     if (side_busy) (void)hipStreamWaitEvent(s, ctx->ev_b, 0);
@@ -229,14 +253,14 @@ void solve_rows_lower(gp_ctx *ctx, double *Vt, int mp, const double *L, int np, 
                 const int rest = c1 - (k0 + GP_NB);
                 if (rest > 0) {
                     gp_prof_begin(ctx, GP_PROF_GEMM);
-                    gpk_gemm_nt(s, mp, rest, GP_NB, -1.0, Vk, mp, L + (size_t)(k0 + GP_NB) + (size_t)k0 * ldl, ldl, 1.0, Vt + (size_t)(k0 + GP_NB) * mp, mp, 0);
+                    gemm_sub_single(s, mp, rest, GP_NB, Vk, mp, L + (size_t)(k0 + GP_NB) + (size_t)k0 * ldl, ldl, Vt + (size_t)(k0 + GP_NB) * mp, mp);
                     gp_prof_end(ctx, GP_PROF_GEMM, 2.0 * mp * (double)rest * GP_NB);
                 }
             }
             const int right = np - c1;
             if (right > 0) {
                 gp_prof_begin(ctx, GP_PROF_GEMM);
-                gpk_gemm_nt(s, mp, right, c1 - c0, -1.0, Vt + (size_t)c0 * mp, mp, L + (size_t)c1 + (size_t)c0 * ldl, ldl, 1.0, Vt + (size_t)c1 * mp, mp, 0);
+                gemm_sub_single(s, mp, right, c1 - c0, Vt + (size_t)c0 * mp, mp, L + (size_t)c1 + (size_t)c0 * ldl, ldl, Vt + (size_t)c1 * mp, mp);
                 gp_prof_end(ctx, GP_PROF_GEMM, 2.0 * mp * (double)right * (c1 - c0));
             }
         }
@@ -288,7 +312,8 @@ void inverse_transpose_lower(gp_ctx *ctx, double *T, const double *L, int np, in
             const int rest = c1 - rows;
             if (rest > 0) {
                 gp_prof_begin(ctx, GP_PROF_GEMM);
-                gpk_gemm_nt(s, rows, rest, GP_NB, -1.0, Tk, np, L + (size_t)rows + (size_t)k0 * ldl, ldl, 1.0, T + (size_t)rows * np, np, 0, 0, bgemm);
+                if (count == 1) gemm_sub_single(s, rows, rest, GP_NB, Tk, np, L + (size_t)rows + (size_t)k0 * ldl, ldl, T + (size_t)rows * np, np);
+                else gpk_gemm_nt(s, rows, rest, GP_NB, -1.0, Tk, np, L + (size_t)rows + (size_t)k0 * ldl, ldl, 1.0, T + (size_t)rows * np, np, 0, 0, bgemm);
                 gp_prof_end(ctx, GP_PROF_GEMM, 2.0 * count * rows * (double)rest * GP_NB);
             }
         }
@@ -501,6 +526,12 @@ const char *gp_last_error(const gp_ctx *ctx) { return ctx ? ctx->err : "null con
 gp_status gp_ctx_profile(gp_ctx *ctx, int mask) {
     if (!ctx || mask < 0 || mask >= (1 << GP_PROF_NCLASSES)) return GP_EINVAL;
     ctx->prof_which = mask;
+    return GP_OK;
+}
+
+gp_status gp_ctx_set_lookahead(gp_ctx *ctx, int mode) {
+    if (!ctx || mode < -1 || mode > 1) return GP_EINVAL;
+    ctx->lookahead = mode;
     return GP_OK;
 }
 

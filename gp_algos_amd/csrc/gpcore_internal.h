@@ -95,6 +95,9 @@ struct gp_batch {
 void gpk_gemm_nt(hipStream_t s, int M, int N, int K, double alpha, const double *A, int lda, const double *B, int ldb,
                  double beta, double *C, int ldc, int lower, int ktri = 0, gp_batch bt = gp_batch(),   // strides: A, B, C
                  const double *Cin = nullptr, int ldcin = 0);   // beta term read from Cin instead of C (C = beta*Cin + alpha*A*B^T, single problem)
+// C (M x N; lower != 0: the lower trapezoid, i >= j on its diagonal tiles) -= A (M x 128) B (N x 128)^T (K a multiple of 32) on 64 x 64 tiles: the
+// latency-bound updates of a single factorisation -- few 128 x 128 tiles, short K (M, N multiples of 64)
+void gpk_gemm_k128_sub(hipStream_t s, int M, int N, const double *A, int lda, const double *B, int ldb, double *C, int ldc, int lower, int K = 128);
 // C[M x 128] = A[M x K] * B[128 x K]^T with fused row reductions (sumsq[m] += sum_n C(m,n)^2, dots[m] += sum_n C(m,n) tvec[n]);
 // C may be the last 128 columns of A (in-place posterior step).
 void gpk_gemm_nt_rowred(hipStream_t s, int M, int N, int K, const double *A, int lda, const double *B, int ldb, double *C, int ldc,

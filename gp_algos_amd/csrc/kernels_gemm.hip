@@ -368,6 +368,86 @@ __global__ __launch_bounds__(WV * 64, 1) void gemm_fused_kernel(int M, int N, in
         }
     }
 }
+
+// C -= A B^T (K a multiple of 32) on 64 x 64 tiles (4 waves x 32 x 32): the in-panel update of the blocked Cholesky
+// (A21 column block -= A21_k A21_k^T confined to one outer panel: r rows x <= 384 columns).  With the general kernel's 128 x 128
+// tiles such a launch is a few hundred workgroups of 14 us of MFMA issue each -- one round, bound by the latency of a single
+// tile, 25 us whatever the size.  Quarter-size tiles put 4x the workgroups on the chip and shorten the dependent chain per
+// workgroup 4x; the operands (the panel the row solve has just written) come from L2, staged through LDS in chunks of 32 k
+// with the next chunk's loads in flight in registers.  LOWER: tiles on/below the diagonal of C only, i >= j stored on its tiles.
+constexpr int SK_T = 64, SK_S = 80, SK_C = 32;
+template <int LOWER>
+__global__ __launch_bounds__(256) void gemm_k128_kernel(int M, int N, int K, const double *__restrict__ A, int lda, const double *__restrict__ B,
+                                                        int ldb, double *__restrict__ C, int ldc) {
+    __shared__ __attribute__((aligned(16))) double as[SK_C * SK_S], bs[SK_C * SK_S];
+    int bi, bj;
+    const int tm = M / SK_T;
+    if (LOWER) {   // column-major enumeration of the lower trapezoid: tile column bj holds rows bj .. tm-1
+        int t = blockIdx.x;
+        bj = 0;
+        while (t >= tm - bj) { t -= tm - bj; ++bj; }
+        bi = bj + t;
+    } else {
+        bi = blockIdx.x % tm;
+        bj = blockIdx.x / tm;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fk = lane >> 4;
+    const int i0 = bi * SK_T, j0 = bj * SK_T, wi = (wave & 1) * 32, wj = (wave >> 1) * 32;
+    const double *Ap = A + i0 + lane + (size_t)wave * lda, *Bp = B + j0 + lane + (size_t)wave * ldb;   // thread: row `lane`, k = wave + 4 q
+    double ra[SK_C / 4], rb[SK_C / 4];
+#pragma unroll
+    for (int q = 0; q < SK_C / 4; ++q) { ra[q] = Ap[(size_t)(4 * q) * lda]; rb[q] = Bp[(size_t)(4 * q) * ldb]; }
+    double4_t acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    for (int kc = 0; kc < K; kc += SK_C) {
+        if (kc) __syncthreads();
+#pragma unroll
+        for (int q = 0; q < SK_C / 4; ++q) { as[(wave + 4 * q) * SK_S + lane] = ra[q]; bs[(wave + 4 * q) * SK_S + lane] = rb[q]; }
+        if (kc + SK_C < K) {
+#pragma unroll
+            for (int q = 0; q < SK_C / 4; ++q) {
+                ra[q] = Ap[(size_t)(kc + SK_C + 4 * q) * lda];
+                rb[q] = Bp[(size_t)(kc + SK_C + 4 * q) * ldb];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < SK_C / 4; ++ks) {
+            double af[2], bf[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                af[t] = as[(4 * ks + fk) * SK_S + wi + 16 * t + fr];     // rows of C
+                bf[t] = bs[(4 * ks + fk) * SK_S + wj + 16 * t + fr];     // columns of C
+            }
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[nt], af[mt], acc[nt][mt], 0, 0, 0);   // reg r: (n = fk + 4 r, m = fr)
+        }
+    }
+    const bool diag_tile = LOWER && (bi == bj);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            double cv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = i0 + wi + 16 * mt + fr, n = j0 + wj + 16 * nt + fk + 4 * r;
+                cv[r] = (diag_tile && m < n) ? 0.0 : C[m + (size_t)n * ldc];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = i0 + wi + 16 * mt + fr, n = j0 + wj + 16 * nt + fk + 4 * r;
+                if (!(diag_tile && m < n)) C[m + (size_t)n * ldc] = cv[r] - acc[nt][mt][r];
+            }
+        }
+}
+
 constexpr int FUSED_LDS = (2 * TK * FSTRIDE + 2 * TK * LDS_STRIDE) * (int)sizeof(double);
 
 // register-only MFMA loop: measures the achievable fp64 matrix-core rate (roofline denominator) with 16
@@ -472,6 +552,14 @@ void gpk_gemm_nt_rowred(hipStream_t s, int M, int N, int K, const double *A, int
         hipLaunchKernelGGL((gemm_nt_f64_kernel<0, 0, 8, 1>), dim3(ntiles), dim3(512), 0, s, M, N, K, 1.0, A, lda, B, ldb, 0.0, C, ldc, 0, gp_batch(), rr, nullptr, 0);
     else
         hipLaunchKernelGGL((gemm_nt_f64_kernel<0, 0, 4, 1>), dim3(ntiles), dim3(256), 0, s, M, N, K, 1.0, A, lda, B, ldb, 0.0, C, ldc, 0, gp_batch(), rr, nullptr, 0);
+}
+
+// C (M x N, lower trapezoid if `lower`) -= A (M x 128) B (N x 128)^T; M, N multiples of 64
+void gpk_gemm_k128_sub(hipStream_t s, int M, int N, const double *A, int lda, const double *B, int ldb, double *C, int ldc, int lower, int K) {
+    if (M <= 0 || N <= 0 || K <= 0) return;
+    const int tm = M / SK_T, tn = N / SK_T;
+    if (lower) hipLaunchKernelGGL(gemm_k128_kernel<1>, dim3(tn * tm - tn * (tn - 1) / 2), dim3(256), 0, s, M, N, K, A, lda, B, ldb, C, ldc);
+    else hipLaunchKernelGGL(gemm_k128_kernel<0>, dim3(tm * tn), dim3(256), 0, s, M, N, K, A, lda, B, ldb, C, ldc);
 }
 
 double gpk_probe_mfma(hipStream_t s, int num_cu, int waves_per_simd, double *clock_mhz, double *cycles_per_mfma) {

@@ -63,6 +63,10 @@ const char *gp_last_error(const gp_ctx *ctx);
 enum { GP_PROF_OFF = 0, GP_PROF_GEMM = 1, GP_PROF_SYRK = 2, GP_PROF_GRAM = 3, GP_PROF_TRSM = 4, GP_PROF_POTRF_DIAG = 5, GP_PROF_PANEL_UPD = 6, GP_PROF_NCLASSES = 7 };
 gp_status gp_ctx_profile(gp_ctx *ctx, int mask);
 gp_status gp_ctx_profile_read(gp_ctx *ctx, int which, int64_t *launches, double *total_ms, double *work);
+/* Look-ahead of the blocked Cholesky (far part of an outer trailing update on the context's CU-masked side stream, under the next
+ * panel's factorisation): 1 on, 0 off, -1 (default) chosen by size.  Per-kernel timings (gp_ctx_profile) of overlapping launches
+ * add up to more than the wall time, so a measurement of the trailing-update kernel alone switches it off. */
+gp_status gp_ctx_set_lookahead(gp_ctx *ctx, int mode);
 /* fp64 MFMA peak probe: runs a register-only v_mfma_f64_16x16x4_f64 loop on every CU and returns
  * the measured TFLOP/s (denominator check for roofline fractions). */
 gp_status gp_probe_mfma_f64(gp_ctx *ctx, double *tflops);
