@@ -378,3 +378,160 @@ JNIEXPORT void JNICALL Java_gpcore_Native_epPredict(JNIEnv *env, jclass k, jlong
     free(P); free(KD); free(KS);
 }
 JNIEXPORT void JNICALL Java_gpcore_Native_epDestroy(JNIEnv *env, jclass k, jlong e) { gp_ep_destroy(EP(e)); }
+
+/* ---- EP hyper-parameter fitting (HyperParamsOptimization.scala:31-55) ---- */
+JNIEXPORT jdouble JNICALL Java_gpcore_Native_epOptimizeRbf(JNIEnv *env, jclass k, jlong h, jdoubleArray x, jint xoff, jint n, jint d, jint ldx,
+                                                           jintArray y, jdoubleArray thetaInOut, jdouble stopEps, jint maxSweeps, jboolean strict,
+                                                           jint maxIter, jint history) {
+    double lml = 0.0;
+    double *X = in_d(env, x, xoff, span(n, d, ldx));
+    jint *Y = X ? in_i(env, y, n) : NULL;
+    double *T0 = Y ? in_d(env, thetaInOut, 0, d + 2) : NULL, *T1 = T0 ? out_d(env, d + 2) : NULL;
+    if (T1) {
+        gp_status st = gp_ep_optimize_rbf(CTX(h), X, n, d, ldx, (const int32_t *)Y, T0, stopEps, maxSweeps, strict ? 1 : 0, maxIter, history, T1, &lml,
+                                          NULL, NULL);
+        if (st != GP_OK) throw_for(env, CTX(h), st, 0); else put_d(env, thetaInOut, 0, T1, d + 2);
+    }
+    free(T1); free(T0); free(Y); free(X);
+    return lml;
+}
+
+/* ---- batched small-n posteriors (GPOptimizer.scala:47-109, GPUnscentedKalmanFilter.scala:63-147) ---- */
+#define SMALL(h) ((gp_small *)(intptr_t)(h))
+JNIEXPORT jlong JNICALL Java_gpcore_Native_smallFit(JNIEnv *env, jclass k, jlong h, jdoubleArray x, jint xoff, jint n, jint d, jint ldx,
+                                                    jdoubleArray y, jint g, jdoubleArray thetas, jdouble sigmaNoiseOrNaN, jint capacity) {
+    double *X = in_d(env, x, xoff, span(n, d, ldx)), *Y = X ? in_d(env, y, 0, (jsize)n * g) : NULL;
+    double *T = Y ? in_d(env, thetas, 0, (jsize)g * (d + 2)) : NULL;
+    gp_small *s = NULL;
+    if (T) {
+        int info = 0;
+        gp_status st = gp_small_fit(CTX(h), X, n, d, ldx, Y, n, g, T, sigmaNoiseOrNaN, capacity, &s, &info);
+        if (st != GP_OK) { throw_for(env, CTX(h), st, info); s = NULL; }
+    }
+    free(T); free(Y); free(X);
+    return (jlong)(intptr_t)s;
+}
+JNIEXPORT void JNICALL Java_gpcore_Native_smallDestroy(JNIEnv *env, jclass k, jlong s) { gp_small_destroy(SMALL(s)); }
+/* mean[g*m], variance[g*m]: model-major */
+JNIEXPORT void JNICALL Java_gpcore_Native_smallPosterior(JNIEnv *env, jclass k, jlong h, jlong s, jint g, jdoubleArray xs, jint xsoff, jint m, jint d,
+                                                         jint ldxs, jdoubleArray mean, jdoubleArray var) {
+    double *XS = in_d(env, xs, xsoff, span(m, d, ldxs)), *ME = XS ? out_d(env, (jsize)g * m) : NULL, *VA = ME ? out_d(env, (jsize)g * m) : NULL;
+    if (VA) {
+        gp_status st = gp_small_posterior(SMALL(s), XS, m, ldxs, ME, VA);
+        if (st != GP_OK) throw_for(env, CTX(h), st, 0); else { put_d(env, mean, 0, ME, (jsize)g * m); put_d(env, var, 0, VA, (jsize)g * m); }
+    }
+    free(VA); free(ME); free(XS);
+}
+JNIEXPORT void JNICALL Java_gpcore_Native_smallUcb(JNIEnv *env, jclass k, jlong h, jlong s, jint g, jdoubleArray xs, jint xsoff, jint m, jint d, jint ldxs,
+                                                   jdouble kappa, jdoubleArray value, jdoubleArray grad) {
+    double *XS = in_d(env, xs, xsoff, span(m, d, ldxs)), *V = XS ? out_d(env, m) : NULL, *G = V ? out_d(env, (jsize)m * d) : NULL;
+    if (G) {
+        gp_status st = gp_small_ucb(SMALL(s), g, XS, m, ldxs, kappa, V, G);
+        if (st != GP_OK) throw_for(env, CTX(h), st, 0); else { put_d(env, value, 0, V, m); put_d(env, grad, 0, G, (jsize)m * d); }
+    }
+    free(G); free(V); free(XS);
+}
+JNIEXPORT void JNICALL Java_gpcore_Native_smallAppend(JNIEnv *env, jclass k, jlong h, jlong s, jint d, jint g, jdoubleArray xNew, jdoubleArray yNew) {
+    double *X = in_d(env, xNew, 0, d), *Y = X ? in_d(env, yNew, 0, g) : NULL;
+    if (Y) {
+        int info = 0;
+        gp_status st = gp_small_append(SMALL(s), X, Y, &info);
+        if (st != GP_OK) throw_for(env, CTX(h), st, info);
+    }
+    free(Y); free(X);
+}
+/* starts: c x d column-major; bestX[d] out; returns the best UCB value */
+JNIEXPORT jdouble JNICALL Java_gpcore_Native_smallMaximizeUcb(JNIEnv *env, jclass k, jlong h, jlong s, jint g, jdoubleArray starts, jint c, jint d,
+                                                              jdouble kappa, jint maxIter, jint history, jdoubleArray bestX) {
+    double best = 0.0;
+    double *S = in_d(env, starts, 0, (jsize)c * d), *B = S ? out_d(env, d) : NULL;
+    if (B) {
+        gp_status st = gp_small_maximize_ucb(SMALL(s), g, S, c, c, kappa, maxIter, history, B, &best, NULL);
+        if (st != GP_OK) throw_for(env, CTX(h), st, 0); else put_d(env, bestX, 0, B, d);
+    }
+    free(B); free(S);
+    return best;
+}
+
+/* ---- Co2Kernel (Co2Prediction.scala:29-137) ---- */
+JNIEXPORT jlong JNICALL Java_gpcore_Native_fitCo2(JNIEnv *env, jclass k, jlong h, jdoubleArray x, jint n, jdoubleArray y, jdoubleArray theta,
+                                                  jdouble sigmaNoiseOrNaN) {
+    double *X = in_d(env, x, 0, n), *Y = X ? in_d(env, y, 0, n) : NULL, *T = Y ? in_d(env, theta, 0, 11) : NULL;
+    gp_model *m = NULL;
+    if (T) {
+        int info = 0;
+        gp_status st = gp_fit_co2(CTX(h), X, n, Y, T, sigmaNoiseOrNaN, &m, &info);
+        if (st != GP_OK) { throw_for(env, CTX(h), st, info); m = NULL; }
+    }
+    free(T); free(Y); free(X);
+    return (jlong)(intptr_t)m;
+}
+JNIEXPORT void JNICALL Java_gpcore_Native_lmlGradCo2Batched(JNIEnv *env, jclass k, jlong h, jdoubleArray x, jint n, jdoubleArray y, jdoubleArray thetas,
+                                                            jint B, jint nparams, jdouble sigmaNoiseOrNaN, jdoubleArray lml, jdoubleArray grad,
+                                                            jintArray info) {
+    double *X = in_d(env, x, 0, n), *Y = X ? in_d(env, y, 0, n) : NULL, *T = Y ? in_d(env, thetas, 0, (jsize)B * 11) : NULL;
+    double *L = T ? out_d(env, B) : NULL, *G = L ? out_d(env, (jsize)B * (nparams > 0 ? nparams : 1)) : NULL;
+    jint *I = G ? calloc((size_t)(B > 0 ? B : 1), sizeof(jint)) : NULL;
+    if (G && !I) throw_for(env, NULL, GP_ENOMEM, 0);
+    if (I) {
+        gp_status st = gp_lml_grad_co2_batched(CTX(h), X, n, Y, T, B, nparams, sigmaNoiseOrNaN, L, G, (int *)I);
+        if (st != GP_OK) throw_for(env, CTX(h), st, 0);
+        else { put_d(env, lml, 0, L, B); put_d(env, grad, 0, G, (jsize)B * nparams); put_i(env, info, I, B); }
+    }
+    free(I); free(G); free(L); free(T); free(Y); free(X);
+}
+JNIEXPORT jdouble JNICALL Java_gpcore_Native_optimizeCo2(JNIEnv *env, jclass k, jlong h, jdoubleArray x, jint n, jdoubleArray y, jdoubleArray thetaInOut,
+                                                         jint nparams, jdouble sigmaNoiseOrNaN, jint maxIter, jint history) {
+    double lml = 0.0;
+    double *X = in_d(env, x, 0, n), *Y = X ? in_d(env, y, 0, n) : NULL, *T0 = Y ? in_d(env, thetaInOut, 0, 11) : NULL, *T1 = T0 ? out_d(env, 11) : NULL;
+    if (T1) {
+        gp_status st = gp_optimize_co2(CTX(h), X, n, Y, T0, nparams, sigmaNoiseOrNaN, maxIter, history, T1, &lml, NULL, NULL);
+        if (st != GP_OK) throw_for(env, CTX(h), st, 0); else put_d(env, thetaInOut, 0, T1, 11);
+    }
+    free(T1); free(T0); free(Y); free(X);
+    return lml;
+}
+
+/* ---- multi-GPU: one JVM per GPU, RCCL (gp_dist_*) ---- */
+#define DIST(h) ((gp_dist *)(intptr_t)(h))
+JNIEXPORT jbyteArray JNICALL Java_gpcore_Native_distUniqueId(JNIEnv *env, jclass k, jlong h) {
+    unsigned char id[GP_DIST_ID_BYTES];
+    gp_status st = gp_dist_unique_id(CTX(h), id);
+    if (st != GP_OK) { throw_for(env, CTX(h), st, 0); return NULL; }
+    jbyteArray out = (*env)->NewByteArray(env, GP_DIST_ID_BYTES);
+    if (out) (*env)->SetByteArrayRegion(env, out, 0, GP_DIST_ID_BYTES, (const jbyte *)id);
+    return out;
+}
+JNIEXPORT jlong JNICALL Java_gpcore_Native_distInit(JNIEnv *env, jclass k, jlong h, jbyteArray id, jint rank, jint world) {
+    unsigned char buf[GP_DIST_ID_BYTES];
+    if (!id || (*env)->GetArrayLength(env, id) != GP_DIST_ID_BYTES) { throw_for(env, NULL, GP_EINVAL, 0); return 0; }
+    (*env)->GetByteArrayRegion(env, id, 0, GP_DIST_ID_BYTES, (jbyte *)buf);
+    gp_dist *d = NULL;
+    gp_status st = gp_dist_init(CTX(h), buf, rank, world, &d);
+    if (st != GP_OK) { throw_for(env, CTX(h), st, 0); return 0; }
+    return (jlong)(intptr_t)d;
+}
+JNIEXPORT void JNICALL Java_gpcore_Native_distDestroy(JNIEnv *env, jclass k, jlong d) { gp_dist_destroy(DIST(d)); }
+JNIEXPORT void JNICALL Java_gpcore_Native_distLmlGradBatched(JNIEnv *env, jclass k, jlong h, jlong dist, jdoubleArray x, jint xoff, jint n, jint d, jint ldx,
+                                                             jdoubleArray y, jdoubleArray thetas, jint B, jint nparams, jdouble sigmaNoiseOrNaN,
+                                                             jdoubleArray lml, jdoubleArray grad, jintArray info) {
+    double *X = in_d(env, x, xoff, span(n, d, ldx)), *Y = X ? in_d(env, y, 0, n) : NULL, *T = Y ? in_d(env, thetas, 0, (jsize)B * (d + 2)) : NULL;
+    double *L = T ? out_d(env, B) : NULL, *G = L ? out_d(env, (jsize)B * (nparams > 0 ? nparams : 1)) : NULL;
+    jint *I = G ? calloc((size_t)(B > 0 ? B : 1), sizeof(jint)) : NULL;
+    if (G && !I) throw_for(env, NULL, GP_ENOMEM, 0);
+    if (I) {
+        gp_status st = gp_dist_lml_grad_batched(DIST(dist), X, n, d, ldx, Y, T, B, nparams, sigmaNoiseOrNaN, L, G, (int *)I);
+        if (st != GP_OK) throw_for(env, CTX(h), st, 0);
+        else { put_d(env, lml, 0, L, B); put_d(env, grad, 0, G, (jsize)B * nparams); put_i(env, info, I, B); }
+    }
+    free(I); free(G); free(L); free(T); free(Y); free(X);
+}
+JNIEXPORT void JNICALL Java_gpcore_Native_distPredict(JNIEnv *env, jclass k, jlong h, jlong dist, jlong model, jdoubleArray xs, jint xsoff, jint m, jint d,
+                                                      jint ldxs, jdoubleArray mean, jdoubleArray var) {
+    double *XS = in_d(env, xs, xsoff, span(m, d, ldxs)), *ME = XS ? out_d(env, m) : NULL, *VA = ME ? out_d(env, m) : NULL;
+    if (VA) {
+        gp_status st = gp_dist_predict(DIST(dist), MODEL(model), XS, m, ldxs, ME, VA);
+        if (st != GP_OK) throw_for(env, CTX(h), st, 0); else { put_d(env, mean, 0, ME, m); put_d(env, var, 0, VA, m); }
+    }
+    free(VA); free(ME); free(XS);
+}

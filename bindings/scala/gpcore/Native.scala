@@ -36,6 +36,24 @@ object Native {
   @native def epGet(ctx: Long, ep: Long, what: Int, out: Array[Double], ld: Int): Unit
   @native def epPredict(ctx: Long, ep: Long, ks: Array[Double], off: Int, m: Int, n: Int, ldks: Int, kssDiag: Array[Double], prob: Array[Double]): Unit
   @native def epDestroy(ep: Long): Unit
+  @native def epOptimizeRbf(ctx: Long, x: Array[Double], xoff: Int, n: Int, d: Int, ldx: Int, y: Array[Int], thetaInOut: Array[Double], stopEps: Double, maxSweeps: Int, strict: Boolean, maxIter: Int, history: Int): Double
+  // batched small-n posteriors: GPOptimizer (GP-UCB), GPUnscentedKalmanFilter (GP-UKF)
+  @native def smallFit(ctx: Long, x: Array[Double], xoff: Int, n: Int, d: Int, ldx: Int, y: Array[Double], g: Int, thetas: Array[Double], sigmaNoiseOrNaN: Double, capacity: Int): Long
+  @native def smallDestroy(small: Long): Unit
+  @native def smallPosterior(ctx: Long, small: Long, g: Int, xs: Array[Double], xsoff: Int, m: Int, d: Int, ldxs: Int, mean: Array[Double], variance: Array[Double]): Unit
+  @native def smallUcb(ctx: Long, small: Long, g: Int, xs: Array[Double], xsoff: Int, m: Int, d: Int, ldxs: Int, kappa: Double, value: Array[Double], grad: Array[Double]): Unit
+  @native def smallAppend(ctx: Long, small: Long, d: Int, g: Int, xNew: Array[Double], yNew: Array[Double]): Unit
+  @native def smallMaximizeUcb(ctx: Long, small: Long, g: Int, starts: Array[Double], c: Int, d: Int, kappa: Double, maxIter: Int, history: Int, bestX: Array[Double]): Double
+  // Co2Kernel
+  @native def fitCo2(ctx: Long, x: Array[Double], n: Int, y: Array[Double], theta: Array[Double], sigmaNoiseOrNaN: Double): Long
+  @native def lmlGradCo2Batched(ctx: Long, x: Array[Double], n: Int, y: Array[Double], thetas: Array[Double], b: Int, nparams: Int, sigmaNoiseOrNaN: Double, lml: Array[Double], grad: Array[Double], info: Array[Int]): Unit
+  @native def optimizeCo2(ctx: Long, x: Array[Double], n: Int, y: Array[Double], thetaInOut: Array[Double], nparams: Int, sigmaNoiseOrNaN: Double, maxIter: Int, history: Int): Double
+  // multi-GPU: one JVM per GPU, RCCL all-gather of the per-rank results
+  @native def distUniqueId(ctx: Long): Array[Byte]
+  @native def distInit(ctx: Long, id: Array[Byte], rank: Int, world: Int): Long
+  @native def distDestroy(dist: Long): Unit
+  @native def distLmlGradBatched(ctx: Long, dist: Long, x: Array[Double], xoff: Int, n: Int, d: Int, ldx: Int, y: Array[Double], thetas: Array[Double], b: Int, nparams: Int, sigmaNoiseOrNaN: Double, lml: Array[Double], grad: Array[Double], info: Array[Int]): Unit
+  @native def distPredict(ctx: Long, dist: Long, model: Long, xs: Array[Double], xsoff: Int, m: Int, d: Int, ldxs: Int, mean: Array[Double], variance: Array[Double]): Unit
 
   /** one context per JVM unless the caller builds its own; device from -Dgpcore.device (default 0) */
   lazy val defaultCtx: Long = ctxCreate(Integer.getInteger("gpcore.device", 0))
