@@ -400,6 +400,35 @@ gp_status gpi_upload_2d(gp_ctx *ctx, double *dst, int ldd, const double *src, in
 gp_status gpi_download_2d(gp_ctx *ctx, double *dst, int ldd, const double *src, int lds, int rows, int cols) { return download_2d(ctx, dst, ldd, src, lds, rows, cols); }
 gp_status gpi_read_info(gp_ctx *ctx, int *info) { return read_info(ctx, info); }
 void gpi_chol_blocked(gp_ctx *ctx, double *A, int np, int lda, double *dinv, int extra) { chol_blocked(ctx, A, np, lda, dinv, extra); }
+
+// Step k0 of chol_blocked (single problem, GP_OUTER-wide outer panels, no look-ahead) on stream s.  Calling it for
+// k0 = 0, 128, ..., np - 128 in order IS the factorisation; the caller may change columns >= k0 between steps (the EP sweep
+// scales block k0's rows and columns when its site precisions become final).  Not profiled per class: the launches are not on
+// the context's stream.
+void gpi_chol_panel_step(gp_ctx *ctx, hipStream_t s, double *A, int np, int lda, double *dinv, int extra, int k0) {
+    const int rows = np + extra;
+    const int K0 = k0 / GP_OUTER * GP_OUTER, wcols = std::min(GP_OUTER, np - K0);
+    double *Akk = A + (size_t)k0 + (size_t)k0 * lda;
+    double *dk = dinv + (size_t)k0 * 16;
+    gpk_potrf_diag128(s, Akk, lda, dk, ctx->d_info, k0, gp_batch());
+    const int r = rows - (k0 + GP_NB);
+    if (r <= 0) return;
+    double *A21 = Akk + GP_NB;
+    gpk_trsm_panel128(s, A21, r, lda, Akk, lda, dk, nullptr, nullptr, nullptr, gp_batch());
+    const int c1 = K0 + wcols, wc = c1 - (k0 + GP_NB);
+    if (wc > 0) {
+        if (small_panel_update()) gpk_gemm_k128_sub(s, r, wc, A21, lda, A21, lda, A21 + (size_t)GP_NB * lda, lda, 1);
+        else gpk_gemm_nt(s, r, wc, GP_NB, -1.0, A21, lda, A21, lda, 1.0, A21 + (size_t)GP_NB * lda, lda, 1);
+        return;
+    }
+    if (np - c1 <= 0) return;
+    const double *P = A + (size_t)c1 + (size_t)K0 * lda;
+    const double tiles128 = trapezoid_flops(rows - c1, np - c1, wcols) / (2.0 * GP_NB * GP_NB * wcols);
+    if (tiles128 < small_update_tiles() && small_panel_update())
+        gpk_gemm_k128_sub(s, rows - c1, np - c1, P, lda, P, lda, A + (size_t)c1 + (size_t)c1 * lda, lda, 1, wcols);
+    else
+        gpk_gemm_nt(s, rows - c1, np - c1, wcols, -1.0, P, lda, P, lda, 1.0, A + (size_t)c1 + (size_t)c1 * lda, lda, 1);
+}
 void gpi_solve_rows_lower(gp_ctx *ctx, double *Vt, int mp, const double *L, int np, int ldl, const double *dinv, double *sumsq,
                           const double *tvec, double *dots) { solve_rows_lower(ctx, Vt, mp, L, np, ldl, dinv, sumsq, tvec, dots); }
 void gpi_inverse_transpose_lower(gp_ctx *ctx, double *T, const double *L, int np, int ldl, const double *dinv) { inverse_transpose_lower(ctx, T, L, np, ldl, dinv); }
@@ -470,6 +499,18 @@ gp_status gp_ctx_create(int device, void *stream, gp_ctx **out) {
             em = hipExtStreamCreateWithCUMask(&ctx->side, (uint32_t)words, mask.data());
         }
         if (em != hipSuccess) { (void)hipGetLastError(); e = hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking); }
+        // second masked stream (same mask): the EP refactorisation that runs under the site loop, beside the site loop's own side work
+        if (e == hipSuccess) {
+            em = hipErrorInvalidValue;
+            if (reserved > 0 && ctx->num_cu >= 64) {
+                const int words = (ctx->num_cu + 31) / 32;
+                std::vector<uint32_t> mask(words, 0xFFFFFFFFu);
+                if (ctx->num_cu % 32) mask[words - 1] = (1u << (ctx->num_cu % 32)) - 1u;
+                for (int i = 0; i < reserved && i < ctx->num_cu; ++i) mask[i / 32] &= ~(1u << (i % 32));
+                em = hipExtStreamCreateWithCUMask(&ctx->side2, (uint32_t)words, mask.data());
+            }
+            if (em != hipSuccess) { (void)hipGetLastError(); e = hipStreamCreateWithFlags(&ctx->side2, hipStreamNonBlocking); }
+        }
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_a, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_b, hipEventDisableTiming);
@@ -499,6 +540,7 @@ void gp_ctx_destroy(gp_ctx *ctx) {
     if (ctx->ev_a) (void)hipEventDestroy(ctx->ev_a);
     if (ctx->ev_b) (void)hipEventDestroy(ctx->ev_b);
     if (ctx->side) (void)hipStreamDestroy(ctx->side);
+    if (ctx->side2) (void)hipStreamDestroy(ctx->side2);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete static_cast<gp_ctx_full *>(ctx);
 }

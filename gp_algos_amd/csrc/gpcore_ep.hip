@@ -26,6 +26,7 @@ struct gp_ep {
     int n = 0, np = 0;
     double *K = nullptr;      // np x np, full symmetric, pad = identity
     double *Sig = nullptr;    // np x np, full symmetric
+    double *Sig2 = nullptr;   // np x np: the NEXT Sigma, built under the site loop by the streamed refactorisation (allocated on first use)
     double *L = nullptr;      // (2 np) x np, ld = ldl = 2 np: rows [0, np) the lower factor of B = I + S^1/2 K S^1/2, rows [np, 2 np) ride through
                               //   the factorisation and come out as Vt = (K S^1/2) L^-T  (V = L \ (S^1/2 K), :59)
     int ldl = 0;
@@ -37,6 +38,7 @@ struct gp_ep {
     double *cvec = nullptr;   // 2 x (128 c + 128 coef), by block parity
     std::vector<hipEvent_t> ev;   // 3 per block: block factor ready | next block's rows solved | side-stream update done
     hipEvent_t ev_chol = nullptr, ev_parta = nullptr, ev_partb = nullptr;   // end-of-sweep refactorisation: see ep_refactor
+    hipEvent_t ev_w = nullptr, ev_pipe = nullptr;   // streamed refactorisation: sweep start on the main stream | its last launch
     bool side_pending = false;    // the side stream still owes the second part of Sigma / mu
     bool sig_mirrored = false;    // the strict upper triangle of Sig mirrors the lower one (only gp_ep_get needs it)
     int *y = nullptr;
@@ -322,6 +324,43 @@ __global__ void ep_bmat_kernel(double *__restrict__ B, int ldb, const double *__
             B[i + (size_t)j * ldb] = (i == j ? 1.0 : 0.0) + (st[i] * st[j]) * K[i + (size_t)j * np];
 }
 
+// ---- streamed refactorisation (gp_ep_sweep): the working matrix W = ep->L, (2 np) x np ----
+// Start of a sweep: rows [0, np) <- K on and below the diagonal, rows [np, 2 np) <- K.  Nothing here depends on the site
+// parameters: with M = K + S^-1 only the DIAGONAL of what is factored depends on them, and B = S^1/2 M S^1/2 means
+// chol(B) = S^1/2 chol(M) -- row i of the factor, of the trailing matrix and of nothing else carries the factor s_i.  So the
+// right-looking factorisation can run on unscaled rows and columns for every site that has not been visited yet.
+__global__ void ep_winit_kernel(double *__restrict__ W, int ldw, const double *__restrict__ K, int np) {
+    for (int j = blockIdx.y; j < np; j += gridDim.y) {
+        const double *kj = K + (size_t)j * np;
+        double *wj = W + (size_t)j * ldw;
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 2 * np; i += gridDim.x * blockDim.x) {
+            if (i >= np) wj[i] = kj[i - np];
+            else if (i >= j) wj[i] = kj[i];
+        }
+    }
+}
+// Site block k0's precisions are final: column k of the block (rows k .. 2 np - 1 of the trailing matrix and of the rows that
+// ride along) takes its factor s_k, rows inside the block take s_i as well, the diagonal gains the identity of B; st <- s.
+__global__ void ep_wscale_cols_kernel(double *__restrict__ W, int ldw, int np, int k0, const double *__restrict__ tau, int n,
+                                      double *__restrict__ st) {
+    const int k = k0 + blockIdx.y;
+    const double sk = (k < n) ? sqrt(tau[k]) : 0.0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) st[k] = sk;
+    double *wk = W + (size_t)k * ldw;
+    for (int i = k + blockIdx.x * blockDim.x + threadIdx.x; i < 2 * np; i += gridDim.x * blockDim.x) {
+        double f = sk;
+        if (i < k0 + GP_NB) f *= (i < n) ? sqrt(tau[i]) : 0.0;
+        const double v = wk[i] * f;
+        wk[i] = (i == k) ? 1.0 + v : v;
+    }
+}
+// ... and the block's rows of the factor computed so far (columns < k0) take s_i
+__global__ void ep_wscale_rows_kernel(double *__restrict__ W, int ldw, int k0, const double *__restrict__ tau, int n) {
+    const int i = k0 + (threadIdx.x & (GP_NB - 1));
+    const double si = (i < n) ? sqrt(tau[i]) : 0.0;
+    for (int j = blockIdx.x * 2 + (threadIdx.x >> 7); j < k0; j += gridDim.x * 2) W[i + (size_t)j * ldw] *= si;
+}
+
 __global__ void mirror_lower_kernel(double *__restrict__ A, int np) {
     __shared__ double t[64][65];
     const int bi = blockIdx.x, bj = blockIdx.y;
@@ -520,6 +559,8 @@ gp_status ep_alloc(gp_ctx *ctx, int n, const int32_t *y, gp_ep **out) {
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ep->ev_chol, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ep->ev_parta, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ep->ev_partb, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ep->ev_w, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ep->ev_pipe, hipEventDisableTiming);
     ep->ev.assign(3 * (np / GP_NB), nullptr);
     for (hipEvent_t &ev : ep->ev)
         if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
@@ -578,7 +619,19 @@ gp_status gp_ep_sweep(gp_ep *ep, int nsweeps, double *tau, double *nu, int *info
     GP_HIP(ctx, hipMemsetAsync(ctx->d_info, 0, sizeof(int), s));
     // GPCORE_EP_OVERLAP=0: every launch of a site block on one stream (the form the overlapped one is tested against)
     const bool overlap = [] { const char *e = getenv("GPCORE_EP_OVERLAP"); return !e || atoi(e) != 0; }();
-    hipStream_t s2 = ctx->side;
+    // GPCORE_EP_PIPELINE: 1 / 0 force the streamed refactorisation on / off; default on from np = 1024 (below that a sweep is
+    // a handful of launches and the end-of-sweep form is as fast)
+    const bool pipe = overlap && np >= 2 * GP_NB && [np] { const char *e = getenv("GPCORE_EP_PIPELINE"); return e ? atoi(e) != 0 : np >= 1024; }();
+    hipStream_t s2 = ctx->side, s3 = ctx->side2;
+    double *partial = nullptr;
+    if (pipe) {
+        if (!ep->Sig2 && hipMalloc(&ep->Sig2, sizeof(double) * (size_t)np * np) != hipSuccess) {
+            (void)hipGetLastError();
+            GP_SET_ERR(ctx, "EP: %d x %d second covariance buffer: out of device memory", np, np);
+            return GP_ENOMEM;
+        }
+        GP_TRY(gpi_ws_get(ctx, WS_PARTIAL, sizeof(double) * (size_t)(SYMV_CHUNKS + 1) * np, &partial));
+    }
     for (int sw = 0; sw < nsweeps; ++sw) {
         // Only the TRAILING part of the recurrence is carried: the sites after a block read mu_i and Sigma_ii "as of now",
         // which depend on the earlier blocks through rows/columns >= their own block only, and the end-of-sweep
@@ -595,6 +648,19 @@ gp_status gp_ep_sweep(gp_ep *ep, int nsweeps, double *tau, double *nu, int *info
         // kernel b+1.  The side stream is CU-masked (gp_ctx_create), so the block kernel, which needs most of a CU's LDS,
         // always finds a free CU.  Small per-block buffers (Lmat, tile inverses, c, coef) alternate by block parity: the
         // side stream still reads block b's while block kernel b+1 writes its own.
+        //
+        // Third stream: the refactorisation of :56-61 runs UNDER the site loop, one block behind it.  A site is visited once per
+        // sweep, so block b's precisions are final when block kernel b ends; with the factor written as chol(B) = S^1/2 chol(K + S^-1)
+        // (ep_winit_kernel) column block b of the right-looking factorisation needs exactly those and nothing later.  Per block:
+        // scale block b's rows and columns of the working matrix, one step of the two-level Cholesky with the np rows of K S^1/2
+        // riding along (-> Vt[:, b] = ((K S^1/2) L^-T)[:, b]), and the rank-128 update  Sigma_next -= Vt[:, b] Vt[:, b]^T  of the
+        // NEXT covariance (second buffer; the site loop still works in the current one).  What is left after the last block
+        // kernel is the last block's own step and mu = Sigma nu.
+        if (pipe) {
+            GP_HIP(ctx, hipEventRecord(ep->ev_w, s));
+            GP_HIP(ctx, hipStreamWaitEvent(s3, ep->ev_w, 0));
+            hipLaunchKernelGGL(ep_winit_kernel, dim3(8, np < 4096 ? np : 4096), dim3(256), 0, s3, ep->L, ep->ldl, ep->K, np);
+        }
         int b = 0;
         hipEvent_t last_side = nullptr;
         for (int i0 = 0; i0 < n; i0 += GP_NB, ++b) {
@@ -604,6 +670,17 @@ gp_status gp_ep_sweep(gp_ep *ep, int nsweeps, double *tau, double *nu, int *info
             double *cvec = ep->cvec + (size_t)par * 2 * GP_NB, *ncoef = cvec + GP_NB;   // c and coef of every site of the block
             hipLaunchKernelGGL(ep_block_kernel, dim3(1), dim3(192), EP_BLOCK_LDS, s, n, np, i0, bsz, ep->Sig, ep->mu(), ep->y,
                                ep->tau(), ep->nu(), ep->cav_tau(), ep->cav_nu(), cvec, ncoef, Lmat, bdinv);
+            hipEvent_t ev_fac = ep->ev[3 * b], ev_rows = ep->ev[3 * b + 1], ev_side = ep->ev[3 * b + 2];
+            if (overlap) GP_HIP(ctx, hipEventRecord(ev_fac, s));
+            if (pipe) {
+                GP_HIP(ctx, hipStreamWaitEvent(s3, ev_fac, 0));
+                hipLaunchKernelGGL(ep_wscale_cols_kernel, dim3((2 * np - i0 + 1023) / 1024, GP_NB), dim3(256), 0, s3, ep->L, ep->ldl, np, i0,
+                                   ep->tau(), n, ep->st());
+                if (i0 > 0) hipLaunchKernelGGL(ep_wscale_rows_kernel, dim3(std::min(i0 / 2, 1024)), dim3(256), 0, s3, ep->L, ep->ldl, i0, ep->tau(), n);
+                gpi_chol_panel_step(ctx, s3, ep->L, np, ep->ldl, ep->dinv, np, i0);
+                const double *Vb = ep->L + np + (size_t)i0 * ep->ldl;
+                gpk_gemm_nt(s3, np, np, GP_NB, -1.0, Vb, ep->ldl, Vb, ep->ldl, 1.0, ep->Sig2, np, 1, 0, gp_batch(), i0 == 0 ? ep->K : nullptr, np);
+            }
             const int r0 = i0 + GP_NB, rt = np - r0;
             if (rt <= 0 || r0 >= n) continue;
             double *St = ep->Sig + (size_t)r0 + (size_t)i0 * np, *Sct = ep->Sc + r0;
@@ -615,10 +692,8 @@ gp_status gp_ep_sweep(gp_ep *ep, int nsweeps, double *tau, double *nu, int *info
                 gp_prof_end(ctx, GP_PROF_GEMM, (double)rt * ((double)rt + GP_NB) * GP_NB);
                 continue;
             }
-            hipEvent_t ev_fac = ep->ev[3 * b], ev_rows = ep->ev[3 * b + 1], ev_side = ep->ev[3 * b + 2];
             const int rest = rt - GP_NB;            // rows from block b+2 on
             if (rest > 0) {
-                GP_HIP(ctx, hipEventRecord(ev_fac, s));
                 GP_HIP(ctx, hipStreamWaitEvent(s2, ev_fac, 0));
                 // side stream, part 1: rows [r0+128, np) of the panel solve and their own lower triangle of the update
                 gpk_trsm_panel128(s2, St + GP_NB, rest, np, Lmat, GP_NB, bdinv, nullptr, ncoef, ep->mu() + r0 + GP_NB, gp_batch(), Sct + GP_NB, cvec);
@@ -640,7 +715,15 @@ gp_status gp_ep_sweep(gp_ep *ep, int nsweeps, double *tau, double *nu, int *info
             last_side = ev_side;
         }
         if (last_side) GP_HIP(ctx, hipStreamWaitEvent(s, last_side, 0));   // the refactorisation rewrites Sigma and mu
-        GP_TRY(ep_refactor(ep));
+        if (pipe) {
+            GP_HIP(ctx, hipEventRecord(ep->ev_pipe, s3));
+            GP_HIP(ctx, hipStreamWaitEvent(s, ep->ev_pipe, 0));
+            std::swap(ep->Sig, ep->Sig2);
+            ep_symv_lower(s, ep->Sig, np, np, ep->nu(), partial, ep->mu(), 0, np);
+            ep->sig_mirrored = false;
+        } else {
+            GP_TRY(ep_refactor(ep));
+        }
         GP_LAUNCH_CHECK(ctx);
         ep->sweeps += 1;
     }
@@ -909,10 +992,13 @@ static gp_status ep_eval_batched(gp_ctx *ctx, const double *X, int n, int d, int
 
 void gp_ep_destroy(gp_ep *ep) {
     if (!ep) return;
-    if (ep->ctx) { (void)hipSetDevice(ep->ctx->device); (void)hipStreamSynchronize(ep->ctx->stream); }
+    if (ep->ctx) {
+        (void)hipSetDevice(ep->ctx->device);
+        for (hipStream_t st : {ep->ctx->stream, ep->ctx->side, ep->ctx->side2}) if (st) (void)hipStreamSynchronize(st);
+    }
     for (hipEvent_t ev : ep->ev) if (ev) (void)hipEventDestroy(ev);
-    for (hipEvent_t ev : {ep->ev_chol, ep->ev_parta, ep->ev_partb}) if (ev) (void)hipEventDestroy(ev);
-    void *ptrs[] = {ep->K, ep->Sig, ep->L, ep->dinv, ep->S, ep->Sc, ep->blk, ep->vec, ep->cvec, ep->y};
+    for (hipEvent_t ev : {ep->ev_chol, ep->ev_parta, ep->ev_partb, ep->ev_w, ep->ev_pipe}) if (ev) (void)hipEventDestroy(ev);
+    void *ptrs[] = {ep->K, ep->Sig, ep->Sig2, ep->L, ep->dinv, ep->S, ep->Sc, ep->blk, ep->vec, ep->cvec, ep->y};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete ep;
 }

@@ -35,6 +35,7 @@ struct gp_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t side = nullptr;      // look-ahead / overlap stream
+    hipStream_t side2 = nullptr;     // second masked stream: the EP refactorisation that runs under the site loop (gp_ep_sweep)
     bool own_stream = false;
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     int prof_which = GP_PROF_OFF;
@@ -166,6 +167,9 @@ gp_status gpi_lbfgs_maximize(gp_ctx *ctx, int P, int nparams, const double *thet
                              const std::function<gp_status(const double *, int, double *, double *, int *)> &evaluate,
                              double *theta_out, double *f_out, int *iters_out, int *evals_out);
 void gpi_chol_blocked(gp_ctx *ctx, double *A, int np, int lda, double *dinv, int extra);
+// one 128-column step (diagonal block k0) of the same two-level factorisation on stream s, for callers that feed the columns
+// one block at a time: diagonal factor, panel solve, in-panel update, and the K = OUTER trailing update when k0 closes an outer panel
+void gpi_chol_panel_step(gp_ctx *ctx, hipStream_t s, double *A, int np, int lda, double *dinv, int extra, int k0);
 void gpi_solve_rows_lower(gp_ctx *ctx, double *Vt, int mp, const double *L, int np, int ldl, const double *dinv, double *sumsq,
                           const double *tvec = nullptr, double *dots = nullptr);
 void gpi_back_solve_vec(gp_ctx *ctx, const double *L, int np, int ldl, const double *dinv, double *z, double *alpha);

@@ -352,6 +352,35 @@ def test_ep_sweeps_vs_oracle(ctx, n, sweeps):
     ep.close()
 
 
+@pytest.mark.parametrize("n,sweeps", [(200, 2), (300, 3), (640, 2), (700, 3)])
+def test_ep_streamed_refactorisation_vs_oracle_and_end_of_sweep_form(ctx, monkeypatch, n, sweeps):
+    """The refactorisation of EpParameterEstimator.scala:56-61 run UNDER the site loop (default from n = 1024; forced here)
+    against the oracle and against the end-of-sweep form: same L, Sigma, mu, site parameters."""
+    from gp_algos_amd import _lib as L
+    from gp_algos_amd.core import EpClassifierState
+    p, K, y = _ep_problem(n, seed=n + 1)
+    o = orc.ep_estimate(K, y, sweeps)
+    got = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("GPCORE_EP_PIPELINE", mode)
+        ep = EpClassifierState(ctx, K, y)
+        tau, nu = ep.sweep(sweeps - 1)
+        tau, nu = ep.sweep(1)            # a second call: the working buffers are re-initialised per sweep
+        got[mode] = dict(tau=tau, nu=nu, mu=ep.get(L.GP_EP_GET_MU), Sigma=ep.get(L.GP_EP_GET_SIGMA), L=ep.get(L.GP_EP_GET_L),
+                         lml=[ep.lml(strict=True), ep.lml(strict=False)])
+        ep.close()
+    for mode, g in got.items():
+        for key in ("tau", "nu", "mu", "Sigma", "L"):
+            assert np.max(np.abs(g[key] - o[key])) <= TOL_EP * np.max(np.abs(o[key])), (mode, key)
+        assert np.all(np.triu(g["L"], 1) == 0.0)
+        assert np.array_equal(g["Sigma"], g["Sigma"].T)
+        for k, strict in enumerate((True, False)):
+            ol = orc.ep_lml(o, y, strict=strict)
+            assert abs(g["lml"][k] - ol) <= 1e-9 * max(1.0, abs(ol))
+    for key in ("tau", "nu", "mu", "Sigma", "L"):
+        assert np.max(np.abs(got["1"][key] - got["0"][key])) <= 1e-11 * np.max(np.abs(got["0"][key])), key
+
+
 def test_ep_sweeps_one_at_a_time_equal_batched(ctx):
     from gp_algos_amd.core import EpClassifierState
     _, K, y = _ep_problem(150, seed=3)
