@@ -404,30 +404,50 @@ void gpi_chol_blocked(gp_ctx *ctx, double *A, int np, int lda, double *dinv, int
 // Step k0 of chol_blocked (single problem, GP_OUTER-wide outer panels, no look-ahead) on stream s.  Calling it for
 // k0 = 0, 128, ..., np - 128 in order IS the factorisation; the caller may change columns >= k0 between steps (the EP sweep
 // scales block k0's rows and columns when its site precisions become final).  Not profiled per class: the launches are not on
-// the context's stream.
-void gpi_chol_panel_step(gp_ctx *ctx, hipStream_t s, double *A, int np, int lda, double *dinv, int extra, int k0) {
+// the context's stream.  `solved` (optional) is recorded when block column k0 of the factor (and of the rows riding along) is final.
+// With a `far` stream (and `solved`, `far_done`) the step that closes an outer panel only updates the NEXT outer panel's columns on s
+// and leaves everything to the right of it to `far`, which starts at `solved` and records `far_done`; the closing step of the next
+// outer panel waits for that event before it touches those columns (the look-ahead of chol_blocked, one step at a time).
+void gpi_chol_panel_step(gp_ctx *ctx, hipStream_t s, double *A, int np, int lda, double *dinv, int extra, int k0, hipEvent_t solved,
+                         hipStream_t far, hipEvent_t far_done) {
     const int rows = np + extra;
     const int K0 = k0 / GP_OUTER * GP_OUTER, wcols = std::min(GP_OUTER, np - K0);
     double *Akk = A + (size_t)k0 + (size_t)k0 * lda;
     double *dk = dinv + (size_t)k0 * 16;
     gpk_potrf_diag128(s, Akk, lda, dk, ctx->d_info, k0, gp_batch());
     const int r = rows - (k0 + GP_NB);
-    if (r <= 0) return;
     double *A21 = Akk + GP_NB;
-    gpk_trsm_panel128(s, A21, r, lda, Akk, lda, dk, nullptr, nullptr, nullptr, gp_batch());
+    if (r > 0) gpk_trsm_panel128(s, A21, r, lda, Akk, lda, dk, nullptr, nullptr, nullptr, gp_batch());
+    if (solved) (void)hipEventRecord(solved, s);
+    if (r <= 0) return;
     const int c1 = K0 + wcols, wc = c1 - (k0 + GP_NB);
     if (wc > 0) {
         if (small_panel_update()) gpk_gemm_k128_sub(s, r, wc, A21, lda, A21, lda, A21 + (size_t)GP_NB * lda, lda, 1);
         else gpk_gemm_nt(s, r, wc, GP_NB, -1.0, A21, lda, A21, lda, 1.0, A21 + (size_t)GP_NB * lda, lda, 1);
         return;
     }
-    if (np - c1 <= 0) return;
+    const int R = np - c1;
+    if (R <= 0) return;
+    const bool split = far && solved && far_done;
+    const int near = split ? std::min(GP_OUTER, R) : R;
+    if (split && K0 > 0) (void)hipStreamWaitEvent(s, far_done, 0);   // the previous outer panel's far update wrote the columns updated below
+    if (R > near) {
+        (void)hipStreamWaitEvent(far, solved, 0);
+        const int c2 = c1 + near;
+        const double *P2 = A + (size_t)c2 + (size_t)K0 * lda;
+        const double tiles = trapezoid_flops(rows - c2, np - c2, wcols) / (2.0 * GP_NB * GP_NB * wcols);
+        if (tiles < small_update_tiles() && small_panel_update())
+            gpk_gemm_k128_sub(far, rows - c2, np - c2, P2, lda, P2, lda, A + (size_t)c2 + (size_t)c2 * lda, lda, 1, wcols);
+        else
+            gpk_gemm_nt(far, rows - c2, np - c2, wcols, -1.0, P2, lda, P2, lda, 1.0, A + (size_t)c2 + (size_t)c2 * lda, lda, 1);
+    }
+    if (split) (void)hipEventRecord(far_done, far);
     const double *P = A + (size_t)c1 + (size_t)K0 * lda;
-    const double tiles128 = trapezoid_flops(rows - c1, np - c1, wcols) / (2.0 * GP_NB * GP_NB * wcols);
+    const double tiles128 = trapezoid_flops(rows - c1, near, wcols) / (2.0 * GP_NB * GP_NB * wcols);
     if (tiles128 < small_update_tiles() && small_panel_update())
-        gpk_gemm_k128_sub(s, rows - c1, np - c1, P, lda, P, lda, A + (size_t)c1 + (size_t)c1 * lda, lda, 1, wcols);
+        gpk_gemm_k128_sub(s, rows - c1, near, P, lda, P, lda, A + (size_t)c1 + (size_t)c1 * lda, lda, 1, wcols);
     else
-        gpk_gemm_nt(s, rows - c1, np - c1, wcols, -1.0, P, lda, P, lda, 1.0, A + (size_t)c1 + (size_t)c1 * lda, lda, 1);
+        gpk_gemm_nt(s, rows - c1, near, wcols, -1.0, P, lda, P, lda, 1.0, A + (size_t)c1 + (size_t)c1 * lda, lda, 1);
 }
 void gpi_solve_rows_lower(gp_ctx *ctx, double *Vt, int mp, const double *L, int np, int ldl, const double *dinv, double *sumsq,
                           const double *tvec, double *dots) { solve_rows_lower(ctx, Vt, mp, L, np, ldl, dinv, sumsq, tvec, dots); }
@@ -499,17 +519,27 @@ gp_status gp_ctx_create(int device, void *stream, gp_ctx **out) {
             em = hipExtStreamCreateWithCUMask(&ctx->side, (uint32_t)words, mask.data());
         }
         if (em != hipSuccess) { (void)hipGetLastError(); e = hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking); }
-        // second masked stream (same mask): the EP refactorisation that runs under the site loop, beside the site loop's own side work
-        if (e == hipSuccess) {
+        // Streams of the EP refactorisation that runs under the site loop, beside the site loop's own side work (gp_ep_sweep).
+        // side3 carries its long GEMMs (far trailing updates, next covariance); GPCORE_RESERVED_CUS_EP (default 96 = 12 per XCD)
+        // CUs are kept free of them, or the site loop's side stream -- whose work the serial chain waits for one block later --
+        // is starved whenever they run (n = 4096 sweeps/s with 32 / 64 / 96 / 128 reserved: 155.7 / 159.7 / 161.9 / 161.2).
+        int reserved_ep = reserved > 0 ? 96 : 0;
+        if (const char *rc = getenv("GPCORE_RESERVED_CUS_EP")) reserved_ep = atoi(rc);
+        // side2 carries the factorisation chain: its workgroups are short-lived (quarter-size tiles) but its single-workgroup
+        // diagonal kernel needs a whole CU's LDS, which it only finds quickly on the CUs the masked streams leave alone -- so side2
+        // itself is NOT masked (GPCORE_EP_CHAIN_MASK=1 masks it like side3)
+        const bool chain_mask = [] { const char *m = getenv("GPCORE_EP_CHAIN_MASK"); return m && atoi(m) != 0; }();
+        for (hipStream_t *sp : {&ctx->side2, &ctx->side3}) {
+            if (e != hipSuccess) break;
             em = hipErrorInvalidValue;
-            if (reserved > 0 && ctx->num_cu >= 64) {
+            if (reserved_ep > 0 && ctx->num_cu >= 64 && (sp != &ctx->side2 || chain_mask)) {
                 const int words = (ctx->num_cu + 31) / 32;
                 std::vector<uint32_t> mask(words, 0xFFFFFFFFu);
                 if (ctx->num_cu % 32) mask[words - 1] = (1u << (ctx->num_cu % 32)) - 1u;
-                for (int i = 0; i < reserved && i < ctx->num_cu; ++i) mask[i / 32] &= ~(1u << (i % 32));
-                em = hipExtStreamCreateWithCUMask(&ctx->side2, (uint32_t)words, mask.data());
+                for (int i = 0; i < reserved_ep && i < ctx->num_cu; ++i) mask[i / 32] &= ~(1u << (i % 32));
+                em = hipExtStreamCreateWithCUMask(sp, (uint32_t)words, mask.data());
             }
-            if (em != hipSuccess) { (void)hipGetLastError(); e = hipStreamCreateWithFlags(&ctx->side2, hipStreamNonBlocking); }
+            if (em != hipSuccess) { (void)hipGetLastError(); e = hipStreamCreateWithFlags(sp, hipStreamNonBlocking); }
         }
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_a, hipEventDisableTiming);
@@ -541,6 +571,7 @@ void gp_ctx_destroy(gp_ctx *ctx) {
     if (ctx->ev_b) (void)hipEventDestroy(ctx->ev_b);
     if (ctx->side) (void)hipStreamDestroy(ctx->side);
     if (ctx->side2) (void)hipStreamDestroy(ctx->side2);
+    if (ctx->side3) (void)hipStreamDestroy(ctx->side3);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete static_cast<gp_ctx_full *>(ctx);
 }

@@ -36,7 +36,7 @@ struct gp_ep {
     double *blk = nullptr;    // 2 x (128 x 128 unit-lower block factor + its 8 tile inverses), by block parity
     double *vec = nullptr;    // 10 x np: tau, nu, tau_old, nu_old, mu, cav_tau, cav_nu, st, tmp1, tmp2
     double *cvec = nullptr;   // 2 x (128 c + 128 coef), by block parity
-    std::vector<hipEvent_t> ev;   // 3 per block: block factor ready | next block's rows solved | side-stream update done
+    std::vector<hipEvent_t> ev;   // 4 per block: block factor ready | next block's rows solved | side-stream update done | Vt block column final
     hipEvent_t ev_chol = nullptr, ev_parta = nullptr, ev_partb = nullptr;   // end-of-sweep refactorisation: see ep_refactor
     hipEvent_t ev_w = nullptr, ev_pipe = nullptr;   // streamed refactorisation: sweep start on the main stream | its last launch
     bool side_pending = false;    // the side stream still owes the second part of Sigma / mu
@@ -561,7 +561,7 @@ gp_status ep_alloc(gp_ctx *ctx, int n, const int32_t *y, gp_ep **out) {
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ep->ev_partb, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ep->ev_w, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ep->ev_pipe, hipEventDisableTiming);
-    ep->ev.assign(3 * (np / GP_NB), nullptr);
+    ep->ev.assign(4 * (np / GP_NB), nullptr);
     for (hipEvent_t &ev : ep->ev)
         if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc(&ep->y, np * sizeof(int));
@@ -622,7 +622,10 @@ gp_status gp_ep_sweep(gp_ep *ep, int nsweeps, double *tau, double *nu, int *info
     // GPCORE_EP_PIPELINE: 1 / 0 force the streamed refactorisation on / off; default on from np = 1024 (below that a sweep is
     // a handful of launches and the end-of-sweep form is as fast)
     const bool pipe = overlap && np >= 2 * GP_NB && [np] { const char *e = getenv("GPCORE_EP_PIPELINE"); return e ? atoi(e) != 0 : np >= 1024; }();
-    hipStream_t s2 = ctx->side, s3 = ctx->side2;
+    hipStream_t s2 = ctx->side, s3 = ctx->side2, s4 = ctx->side3;
+    const bool far_split = [] { const char *e = getenv("GPCORE_EP_FAR"); return !e || atoi(e) != 0; }();
+    const bool sig_small = [] { const char *e = getenv("GPCORE_EP_SIG_K128"); return e && atoi(e) != 0; }();
+    const int nblk = np / GP_NB;
     double *partial = nullptr;
     if (pipe) {
         if (!ep->Sig2 && hipMalloc(&ep->Sig2, sizeof(double) * (size_t)np * np) != hipSuccess) {
@@ -659,9 +662,10 @@ gp_status gp_ep_sweep(gp_ep *ep, int nsweeps, double *tau, double *nu, int *info
         if (pipe) {
             GP_HIP(ctx, hipEventRecord(ep->ev_w, s));
             GP_HIP(ctx, hipStreamWaitEvent(s3, ep->ev_w, 0));
+            GP_HIP(ctx, hipStreamWaitEvent(s4, ep->ev_w, 0));
             hipLaunchKernelGGL(ep_winit_kernel, dim3(8, np < 4096 ? np : 4096), dim3(256), 0, s3, ep->L, ep->ldl, ep->K, np);
         }
-        int b = 0;
+        int b = 0, pend0 = 0;   // pend0: first column of Vt not yet in the next covariance
         hipEvent_t last_side = nullptr;
         for (int i0 = 0; i0 < n; i0 += GP_NB, ++b) {
             const int bsz = (n - i0 < GP_NB) ? n - i0 : GP_NB;
@@ -670,16 +674,24 @@ gp_status gp_ep_sweep(gp_ep *ep, int nsweeps, double *tau, double *nu, int *info
             double *cvec = ep->cvec + (size_t)par * 2 * GP_NB, *ncoef = cvec + GP_NB;   // c and coef of every site of the block
             hipLaunchKernelGGL(ep_block_kernel, dim3(1), dim3(192), EP_BLOCK_LDS, s, n, np, i0, bsz, ep->Sig, ep->mu(), ep->y,
                                ep->tau(), ep->nu(), ep->cav_tau(), ep->cav_nu(), cvec, ncoef, Lmat, bdinv);
-            hipEvent_t ev_fac = ep->ev[3 * b], ev_rows = ep->ev[3 * b + 1], ev_side = ep->ev[3 * b + 2];
+            hipEvent_t ev_fac = ep->ev[4 * b], ev_rows = ep->ev[4 * b + 1], ev_side = ep->ev[4 * b + 2], ev_vt = ep->ev[4 * b + 3];
             if (overlap) GP_HIP(ctx, hipEventRecord(ev_fac, s));
             if (pipe) {
                 GP_HIP(ctx, hipStreamWaitEvent(s3, ev_fac, 0));
                 hipLaunchKernelGGL(ep_wscale_cols_kernel, dim3((2 * np - i0 + 1023) / 1024, GP_NB), dim3(256), 0, s3, ep->L, ep->ldl, np, i0,
                                    ep->tau(), n, ep->st());
                 if (i0 > 0) hipLaunchKernelGGL(ep_wscale_rows_kernel, dim3(std::min(i0 / 2, 1024)), dim3(256), 0, s3, ep->L, ep->ldl, i0, ep->tau(), n);
-                gpi_chol_panel_step(ctx, s3, ep->L, np, ep->ldl, ep->dinv, np, i0);
-                const double *Vb = ep->L + np + (size_t)i0 * ep->ldl;
-                gpk_gemm_nt(s3, np, np, GP_NB, -1.0, Vb, ep->ldl, Vb, ep->ldl, 1.0, ep->Sig2, np, 1, 0, gp_batch(), i0 == 0 ? ep->K : nullptr, np);
+                gpi_chol_panel_step(ctx, s3, ep->L, np, ep->ldl, ep->dinv, np, i0, ev_vt, far_split ? s4 : nullptr, ep->ev_parta);
+                // the finished columns of Vt go into the next covariance on a stream of their own, an outer panel (K = 512) at a time;
+                // the last outer panel in two pieces so that only a K = 128 update is left after the last block kernel
+                if ((b + 1) % (GP_OUTER / GP_NB) == 0 || b >= nblk - 2) {
+                    GP_HIP(ctx, hipStreamWaitEvent(s4, ev_vt, 0));
+                    const int kw = i0 + GP_NB - pend0;
+                    const double *Vb = ep->L + np + (size_t)pend0 * ep->ldl;
+                    if (pend0 > 0 && sig_small) gpk_gemm_k128_sub(s4, np, np, Vb, ep->ldl, Vb, ep->ldl, ep->Sig2, np, 1, kw);
+                    else gpk_gemm_nt(s4, np, np, kw, -1.0, Vb, ep->ldl, Vb, ep->ldl, 1.0, ep->Sig2, np, 1, 0, gp_batch(), pend0 == 0 ? ep->K : nullptr, np);
+                    pend0 = i0 + GP_NB;
+                }
             }
             const int r0 = i0 + GP_NB, rt = np - r0;
             if (rt <= 0 || r0 >= n) continue;
@@ -702,7 +714,7 @@ gp_status gp_ep_sweep(gp_ep *ep, int nsweeps, double *tau, double *nu, int *info
                 gp_prof_end(ctx, GP_PROF_GEMM, (double)rest * ((double)rest + GP_NB) * GP_NB, s2);
             }
             // main stream: the 128 rows of block b+1 -- they read Sigma entries the side stream's update of block b-1 wrote
-            if (b > 0) GP_HIP(ctx, hipStreamWaitEvent(s, ep->ev[3 * (b - 1) + 2], 0));
+            if (b > 0) GP_HIP(ctx, hipStreamWaitEvent(s, ep->ev[4 * (b - 1) + 2], 0));
             gpk_trsm_panel128(s, St, GP_NB, np, Lmat, GP_NB, bdinv, nullptr, ncoef, ep->mu() + r0, gp_batch(), Sct, cvec);
             hipLaunchKernelGGL(ep_diag_update_kernel, dim3(36), dim3(64), 0, s, Ctr, np, Sct, St, np);
             if (rest > 0) {
@@ -716,8 +728,10 @@ gp_status gp_ep_sweep(gp_ep *ep, int nsweeps, double *tau, double *nu, int *info
         }
         if (last_side) GP_HIP(ctx, hipStreamWaitEvent(s, last_side, 0));   // the refactorisation rewrites Sigma and mu
         if (pipe) {
-            GP_HIP(ctx, hipEventRecord(ep->ev_pipe, s3));
+            GP_HIP(ctx, hipEventRecord(ep->ev_pipe, s4));   // s4's last update waited for s3's last panel solve
             GP_HIP(ctx, hipStreamWaitEvent(s, ep->ev_pipe, 0));
+            GP_HIP(ctx, hipEventRecord(ep->ev_chol, s3));   // (the last step has no update after its solve; kept for symmetry)
+            GP_HIP(ctx, hipStreamWaitEvent(s, ep->ev_chol, 0));
             std::swap(ep->Sig, ep->Sig2);
             ep_symv_lower(s, ep->Sig, np, np, ep->nu(), partial, ep->mu(), 0, np);
             ep->sig_mirrored = false;
@@ -994,7 +1008,7 @@ void gp_ep_destroy(gp_ep *ep) {
     if (!ep) return;
     if (ep->ctx) {
         (void)hipSetDevice(ep->ctx->device);
-        for (hipStream_t st : {ep->ctx->stream, ep->ctx->side, ep->ctx->side2}) if (st) (void)hipStreamSynchronize(st);
+        for (hipStream_t st : {ep->ctx->stream, ep->ctx->side, ep->ctx->side2, ep->ctx->side3}) if (st) (void)hipStreamSynchronize(st);
     }
     for (hipEvent_t ev : ep->ev) if (ev) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : {ep->ev_chol, ep->ev_parta, ep->ev_partb, ep->ev_w, ep->ev_pipe}) if (ev) (void)hipEventDestroy(ev);

@@ -35,7 +35,8 @@ struct gp_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t side = nullptr;      // look-ahead / overlap stream
-    hipStream_t side2 = nullptr;     // second masked stream: the EP refactorisation that runs under the site loop (gp_ep_sweep)
+    hipStream_t side2 = nullptr;     // second and third masked streams: the EP refactorisation that runs under the site loop (gp_ep_sweep):
+    hipStream_t side3 = nullptr;     //   side2 the factorisation chain, side3 the rank-k updates of the next covariance
     bool own_stream = false;
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     int prof_which = GP_PROF_OFF;
@@ -169,7 +170,8 @@ gp_status gpi_lbfgs_maximize(gp_ctx *ctx, int P, int nparams, const double *thet
 void gpi_chol_blocked(gp_ctx *ctx, double *A, int np, int lda, double *dinv, int extra);
 // one 128-column step (diagonal block k0) of the same two-level factorisation on stream s, for callers that feed the columns
 // one block at a time: diagonal factor, panel solve, in-panel update, and the K = OUTER trailing update when k0 closes an outer panel
-void gpi_chol_panel_step(gp_ctx *ctx, hipStream_t s, double *A, int np, int lda, double *dinv, int extra, int k0);
+void gpi_chol_panel_step(gp_ctx *ctx, hipStream_t s, double *A, int np, int lda, double *dinv, int extra, int k0, hipEvent_t solved = nullptr,
+                         hipStream_t far = nullptr, hipEvent_t far_done = nullptr);
 void gpi_solve_rows_lower(gp_ctx *ctx, double *Vt, int mp, const double *L, int np, int ldl, const double *dinv, double *sumsq,
                           const double *tvec = nullptr, double *dots = nullptr);
 void gpi_back_solve_vec(gp_ctx *ctx, const double *L, int np, int ldl, const double *dinv, double *z, double *alpha);
