@@ -25,6 +25,12 @@ constexpr int NB = GP_NB;   // 128
 constexpr int PLS = 144;    // LDS column stride of the 128x128 block: 1152 B = 128 (mod 256) -> conflict-free fragments
 constexpr int XS = 80;      // LDS column stride of the 64-row X strip: 640 B = 128 (mod 256)
 constexpr int LS1 = NB + 1;
+#ifndef POTRF_DPP
+#define POTRF_DPP 1   // 16 x 16 tile factorisation with DPP row broadcasts (0: v_readlane / LDS-broadcast form)
+#endif
+#ifndef POTRF_NR2
+#define POTRF_NR2 0   // second Newton step on v_rsq_f64 in the tile pivots: not needed, the sqrt and reciprocal corrections that follow are Newton steps themselves
+#endif
 
 __device__ __forceinline__ double rl64(double v, int lane) {
     int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
@@ -34,20 +40,91 @@ __device__ __forceinline__ double rl64(double v, int lane) {
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 
+// d -= a(lane C of this lane's 16-lane row) * b: ONE DPP instruction (row_newbcast on a 64-bit VALU op) where the portable form
+// costs two v_readlane + an FMA.  A DPP read needs 2 wait states after a VALU write of the same VGPR and the hazard recogniser
+// does not look inside inline asm: the FIRST use of a freshly written `a` goes through fnma_bcast_first, which carries the s_nop
+// and passes `a` through as an output, so that every later use depends on it and cannot be scheduled ahead of it.
+template <int C>
+__device__ __forceinline__ void fnma_bcast_first(double &d, double &a, double b) {
+    asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(d), "+v"(a) : "v"(b), "n"(C));
+}
+template <int C>
+__device__ __forceinline__ void fnma_bcast(double &d, double a, double b) {
+    asm("v_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(d) : "v"(a), "v"(b), "n"(C));
+}
+// lane C of this lane's 16-lane row, copied to every lane of the row
+template <int C>
+__device__ __forceinline__ double bcast_row(double a) {
+    double d;
+    asm("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(d) : "v"(a), "n"(C));
+    return d;
+}
+// trailing columns of step J of the 16 x 16 tile factorisation: row[c] -= row[J] * L(c, J), c = C .. 15
+template <int J, int C>
+__device__ __forceinline__ void tile_update_cols(double (&row)[16], double lj) {
+    if constexpr (C < 16) {
+        fnma_bcast<C>(row[C], lj, lj);
+        tile_update_cols<J, C + 1>(row, lj);
+    }
+}
+// step J of the inverse, right-looking: s[rr] -= L(rr, J) x[J], rr = RR .. 15, with L(rr, J) = row[J] of lane rr
+template <int J, int RR>
+__device__ __forceinline__ void tile_inv_update(double (&s)[16], double lj, double xj) {
+    if constexpr (RR < 16) {
+        fnma_bcast<RR>(s[RR], lj, xj);
+        tile_inv_update<J, RR + 1>(s, lj, xj);
+    }
+}
+// Column J of the 16 x 16 tile Cholesky (row owner = lane & 15, replicated in the four 16-lane rows of the wave) together
+// with step J of the tile inverse X = L^-1 (column owner = lane & 15).  Both are chains of DEPENDENT fp64 operations
+// (~16 cycles each on this hardware, measured: the factorisation alone 219 cycles per column, the inverse as much again when it
+// ran afterwards), so (i) the pivot chain is as short as it can be made: v_rsq_f64 and two Newton steps give rs = 1/sqrt(a_jj) to
+// an ulp or two, the column is scaled by rs directly (no divide, no dependence on the rounded diagonal), and the diagonal
+// sqrt(a_jj) = a_jj rs with its correction is computed beside the chain; (ii) the inverse is written right-looking,
+// x[J] = s[J] rs and s[rr] -= L(rr, J) x[J], which needs nothing but column J -- its instructions fill the issue slots the pivot
+// chain leaves empty; (iii) every cross-lane operand is a DPP row broadcast folded into the FMA (fnma_bcast).
+// The diagonal needs no special case: for lane J, row[J] = a_jj, so a_jj rs is sqrt(a_jj) to an ulp or two.
+// A non-positive pivot is not replaced: 1/sqrt turns it into NaN or +-inf, which reaches `guard` (the running sum of the rs),
+// the caller tests that ONE number, and only then looks for the first offender among the pivots kept in piv[] -- the common
+// path carries one add per column instead of a compare-and-select chain.
+template <int J>
+__device__ __forceinline__ void tile_chol_inv_cols(double (&row)[16], double (&s)[16], double (&x)[16], double (&piv)[16], double &guard) {
+    if constexpr (J < 16) {
+        const double ajj = bcast_row<J>(row[J]);
+        piv[J] = ajj;
+        double rs = __builtin_amdgcn_rsq(ajj);
+        double e = fma(-(ajj * rs), rs, 1.0);
+        rs = fma(0.5 * rs, e, rs);
+        const double t = ajj * rs;               // ~ sqrt(a_jj)
+        e = fma(-t, rs, 1.0);
+        rs = fma(0.5 * rs, e, rs);
+        guard += rs;
+        double lj = row[J] * rs;                 // L(i, J) for the rows below the diagonal (lanes i > J), sqrt(a_jj) on lane J
+        x[J] = s[J] * rs;
+        if constexpr (J < 15) {
+            fnma_bcast_first<J + 1>(row[J + 1], lj, lj);     // the next pivot column first
+            tile_update_cols<J, J + 2>(row, lj);
+            tile_inv_update<J, J + 1>(s, lj, x[J]);
+        }
+        row[J] = lj;
+        tile_chol_inv_cols<J + 1>(row, s, x, piv, guard);
+    }
+}
+
 // 128x128 block global -> LDS with 16-byte loads, 8 in flight per thread (a serial load/wait/ds_write loop
 // costs ~45 us for this block; batched it is ~2 us).  LOWER: zero the strict upper triangle on the way in.
-template <int STRIDE, bool LOWER>
+template <int STRIDE, bool LOWER, int INFLIGHT = 8>
 __device__ __forceinline__ void load_block_lds(double *a, const double *__restrict__ A, int lda, int tid) {
 #pragma unroll
-    for (int q0 = 0; q0 < 32; q0 += 8) {
-        double2_t v[8];
+    for (int q0 = 0; q0 < 32; q0 += INFLIGHT) {
+        double2_t v[INFLIGHT];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < INFLIGHT; ++q) {
             const int e = tid + 256 * (q0 + q), i = (e & 63) * 2, j = e >> 6;
             v[q] = *reinterpret_cast<const double2_t *>(A + i + (size_t)j * lda);
         }
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < INFLIGHT; ++q) {
             const int e = tid + 256 * (q0 + q), i = (e & 63) * 2, j = e >> 6;
             a[i + j * STRIDE] = (!LOWER || i >= j) ? v[q].x : 0.0;
             a[i + 1 + j * STRIDE] = (!LOWER || i + 1 >= j) ? v[q].y : 0.0;
@@ -55,8 +132,23 @@ __device__ __forceinline__ void load_block_lds(double *a, const double *__restri
     }
 }
 
+#ifdef POTRF_STAMPS   // tools/lab/potrf_lab.hip: cycle stamps of the phases of one launch (never defined in the library build)
+__device__ unsigned long long potrf_stamps[256];
+#define STAMP(slot) do { if (lane == 0) potrf_stamps[(slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(slot) do { } while (0)
+#endif
+
 // -------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void potrf_diag128_kernel(double *__restrict__ A, int lda, double *__restrict__ dinv,
+// tile index q of a lower-triangular enumeration -> (bi, bj), bi >= bj
+__device__ __forceinline__ void tri_coords(int q, int &bi, int &bj) {
+    bi = 0;
+    while ((bi + 1) * (bi + 2) / 2 <= q) ++bi;
+    bj = q - bi * (bi + 1) / 2;
+}
+
+constexpr int POTRF_WAVES = 8;   // wave 0: the serial chain; the others: panel, update and stores (two waves per SIMD hide each other's LDS / MFMA latency)
+__global__ __launch_bounds__(64 * POTRF_WAVES) void potrf_diag128_kernel(double *__restrict__ A, int lda, double *__restrict__ dinv,
                                                             int *info, int base, gp_batch bt) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     A += (size_t)blockIdx.x * bt.s0;      // one workgroup per problem of a lockstep batch
@@ -68,66 +160,65 @@ __global__ __launch_bounds__(256) void potrf_diag128_kernel(double *__restrict__
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
     if (tid == 0) *flag = 0;
-    load_block_lds<PLS, true>(a, A, lda, tid);
-    __syncthreads();
-    // Two barriers per micro-panel.  Wave 0 owns the serial part (tile Cholesky + tile inverse, ~3 us) and, of the update that
-    // follows a panel, only the ONE tile it needs next (the following diagonal tile); the other 3 waves apply the rest of that
-    // update while wave 0 is already factoring -- everybody meets again at the barrier after the factorisation.
+    if (wave == 0) STAMP(0);
+    // Load by LDS-DMA: one wave instruction moves one 128-double column (64 lanes x 16 B, contiguous in LDS, the pad follows it),
+    // no staging VGPRs, everything in flight at once.  This kernel is a chain link -- nothing else hides its loads, and one CU
+    // pulls ~50 GB/s, so (i) only the part on and below the diagonal is fetched (lanes above it are masked off; nothing below
+    // reads the strict upper triangle: the tile factorisation writes zeros above the diagonal of the diagonal tiles, panel and
+    // update steps only touch tiles on or below the diagonal, the stores mask i < j), and (ii) wave 0 fetches just the first
+    // 16 columns and starts factoring while the other three waves bring in the rest.
+    {
+        const double *src = A + lane * 2;
+        if (wave == 0) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if (lane * 2 + 1 >= j) __builtin_amdgcn_global_load_lds(src + (size_t)j * lda, a + j * PLS, 16, 0, 0);
+        } else {
+            for (int j = 16 + (wave - 1); j < NB; j += POTRF_WAVES - 1)
+                if (lane * 2 + 1 >= j) __builtin_amdgcn_global_load_lds(src + (size_t)j * lda, a + j * PLS, 16, 0, 0);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's columns are in LDS
+    }
+    if (wave == 0) STAMP(1);
+    // Two barriers per micro-panel.  Wave 0 owns the serial part (tile Cholesky + tile inverse) and, of the update that follows a
+    // panel, only the ONE tile it needs next (the following diagonal tile); the other 3 waves apply the rest of that update and
+    // write the finished 16 columns out while wave 0 is already factoring -- everybody meets again at the barrier after the
+    // factorisation.
     for (int jb = 0; jb < NB / 16; ++jb) {
         const int c0 = jb * 16;
         if (wave == 0) {
-            // ---- 16x16 tile: Cholesky (row owner = lane&15) then inverse (column owner = lane&15) ----
-            double row[16], invd[16], x[16];
+            // ---- 16x16 tile: Cholesky (row owner = lane&15) and inverse (column owner = lane&15) in one pass ----
+            double row[16], x[16], sv[16];
 #pragma unroll
             for (int c = 0; c < 16; ++c) row[c] = a[(c0 + fr) + (c0 + c) * PLS];
-            int bad = 0;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                double ajj = rl64(row[j], j);
-                if (!(ajj > 0.0)) { if (!bad) bad = j + 1; ajj = 1.0; }
-                // 1/sqrt by v_rsq_f64 + two Newton steps, sqrt = a*r with one correction: ~10 dependent FMAs
-                // instead of the ~45-instruction sqrt + divide pair (this chain is on the critical path 16x per tile)
-                double rs = __builtin_amdgcn_rsq(ajj);
-                rs = rs * fma(-0.5 * ajj * rs, rs, 1.5);
-                rs = rs * fma(-0.5 * ajj * rs, rs, 1.5);
-                double djj = ajj * rs;
-                djj = fma(0.5 * rs, fma(-djj, djj, ajj), djj);
-                const double inv = fma(rs, fma(-djj, rs, 1.0), rs);   // 1/djj refined against the rounded djj
-                invd[j] = inv;
-                row[j] = (fr == j) ? djj : row[j] * inv;
-#pragma unroll
-                for (int c = j + 1; c < 16; ++c) {
-                    const double lcj = rl64(row[j], c);
-                    row[c] = fma(-row[j], lcj, row[c]);
-                }
-            }
+            for (int rr = 0; rr < 16; ++rr) sv[rr] = (rr == fr) ? 1.0 : 0.0;
+            double piv[16], guard = 0.0;
+            STAMP(8 + 8 * jb + 0);
+            tile_chol_inv_cols<0>(row, sv, x, piv, guard);
+            STAMP(8 + 8 * jb + 1);
             if (lane < 16) {
+                // (what lands above the diagonal of the tile is never read: the stores to global memory mask it)
 #pragma unroll
-                for (int c = 0; c < 16; ++c) a[(c0 + fr) + (c0 + c) * PLS] = (c <= fr) ? row[c] : 0.0;
+                for (int c = 0; c < 16; ++c) a[(c0 + fr) + (c0 + c) * PLS] = row[c];
+#pragma unroll
+                for (int rr = 0; rr < 16; ++rr) dv[rr + 16 * fr] = x[rr];
             }
-            // inverse, column owner = lane&15; D(rr,k) comes back as an LDS broadcast (same address in every lane)
+            if (!(fabs(guard) < HUGE_VAL)) {     // a pivot was <= 0 or NaN (rare): which one came first
+                int bad = 0;
 #pragma unroll
-            for (int rr = 0; rr < 16; ++rr) {
-                double s = (rr == fr) ? 1.0 : 0.0;
-#pragma unroll
-                for (int k = 0; k < rr; ++k) s = fma(-a[(c0 + rr) + (c0 + k) * PLS], x[k], s);
-                x[rr] = s * invd[rr];
+                for (int j = 15; j >= 0; --j) if (!(piv[j] > 0.0)) bad = j + 1;
+                if (lane == 0) { atomicCAS(info, 0, base + c0 + bad); *flag = 1; }
             }
-            if (lane < 16) {
-#pragma unroll
-                for (int rr = 0; rr < 16; ++rr) {
-                    dv[rr + 16 * fr] = x[rr];
-                    dinv[jb * 256 + rr + 16 * fr] = x[rr];
-                }
-            }
-            if (bad && lane == 0) { atomicCAS(info, 0, base + c0 + bad); *flag = 1; }
+            STAMP(8 + 8 * jb + 2);
         }
         __syncthreads();
+        if (wave == 0) STAMP(8 + 8 * jb + 3);
         if (*flag) break;
         // ---- panel below the tile:  P <- A_below * invD^T, computed as (invD * A_below^T) so rows stay on the lane ----
         const int T = NB / 16 - 1 - jb;
-        for (int t = wave; t < T; t += 4) {
-            const int r0 = c0 + 16 + 16 * t;
+        if (wave < T) {    // T <= 7 tiles, one per wave
+            const int r0 = c0 + 16 + 16 * wave;
             double4_t acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
@@ -138,37 +229,60 @@ __global__ __launch_bounds__(256) void potrf_diag128_kernel(double *__restrict__
 #pragma unroll
             for (int r = 0; r < 4; ++r) a[(r0 + fr) + (c0 + fg + 4 * r) * PLS] = acc[r];
         }
-        __syncthreads();
-        // ---- rest of the block:  A(ti,tj) -= P_ti P_tj^T  for jb < tj <= ti ----
-        const int ntile = T * (T + 1) / 2;
-        for (int q = (wave == 0 ? 0 : wave); q < (wave == 0 ? (ntile > 0 ? 1 : 0) : ntile); q += 3) {
-            int bi = 0;
-            while ((bi + 1) * (bi + 2) / 2 <= q) ++bi;
-            const int bj = q - bi * (bi + 1) / 2;
-            const int ri = c0 + 16 + 16 * bi, rj = c0 + 16 + 16 * bj;
-            double4_t acc;
+        if (wave == POTRF_WAVES - 1) {   // the tile inverse also goes out to global memory (the panel solves of the other kernels): off wave 0's chain
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[r] = a[(ri + fr) + (rj + fg + 4 * r) * PLS];
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const double aop = -a[(rj + fr) + (c0 + 4 * ks + fg) * PLS];
-                const double bop = a[(ri + fr) + (c0 + 4 * ks + fg) * PLS];
-                acc = MFMA(aop, bop, acc);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) a[(ri + fr) + (rj + fg + 4 * r) * PLS] = acc[r];
+            for (int q = 0; q < 4; ++q) dinv[jb * 256 + lane + 64 * q] = dv[lane + 64 * q];
         }
+        if (wave == 0) STAMP(8 + 8 * jb + 4);
+        __syncthreads();
+        if (wave == 0) STAMP(8 + 8 * jb + 5);
+        // ---- rest of the block:  A(ti,tj) -= P_ti P_tj^T  for jb < tj <= ti; wave 0 only the next diagonal tile ----
+        const int ntile = T * (T + 1) / 2;
+        if (wave == 0) {
+            if (ntile > 0) {
+                const int ri = c0 + 16;
+                double4_t acc;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] = a[(ri + fr) + (ri + fg + 4 * r) * PLS];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const double bop = a[(ri + fr) + (c0 + 4 * ks + fg) * PLS];
+                    acc = MFMA(-bop, bop, acc);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) a[(ri + fr) + (ri + fg + 4 * r) * PLS] = acc[r];
+            }
+        } else {
+            for (int q = wave; q < ntile; q += POTRF_WAVES - 1) {
+                int bi, bj;
+                tri_coords(q, bi, bj);
+                const int ri = c0 + 16 + 16 * bi, rj = c0 + 16 + 16 * bj;
+                double4_t acc;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] = a[(ri + fr) + (rj + fg + 4 * r) * PLS];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const double aop = -a[(rj + fr) + (c0 + 4 * ks + fg) * PLS];
+                    const double bop = a[(ri + fr) + (c0 + 4 * ks + fg) * PLS];
+                    acc = MFMA(aop, bop, acc);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) a[(ri + fr) + (rj + fg + 4 * r) * PLS] = acc[r];
+            }
+            // columns c0 .. c0+15 are final (diagonal tile before the first barrier, the panel before the second): out they go,
+            // zeros above the diagonal, while wave 0 factors the next tile
+            for (int e = tid - 64; e < 16 * 64; e += 64 * (POTRF_WAVES - 1)) {
+                const int i = (e & 63) * 2, j = c0 + (e >> 6);
+                double2_t v;
+                v.x = (i >= j) ? a[i + j * PLS] : 0.0;
+                v.y = (i + 1 >= j) ? a[i + 1 + j * PLS] : 0.0;
+                *reinterpret_cast<double2_t *>(A + i + (size_t)j * lda) = v;
+            }
+        }
+        if (wave == 0) STAMP(8 + 8 * jb + 6);
+        if (wave == 1) STAMP(128 + jb);
     }
-    __syncthreads();
-    if (*flag) return;
-#pragma unroll 8
-    for (int q = 0; q < 32; ++q) {
-        const int e = tid + 256 * q, i = (e & 63) * 2, j = e >> 6;
-        double2_t v;
-        v.x = (i >= j) ? a[i + j * PLS] : 0.0;
-        v.y = (i + 1 >= j) ? a[i + 1 + j * PLS] : 0.0;
-        *reinterpret_cast<double2_t *>(A + i + (size_t)j * lda) = v;
-    }
+    if (wave == 0) { STAMP(2); STAMP(3); }
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -399,7 +513,7 @@ int gpk_init_diag_kernels() {
 
 void gpk_potrf_diag128(hipStream_t s, double *A, int lda, double *dinv, int *d_info, int base, gp_batch bt) {
     if (bt.count <= 0) return;
-    hipLaunchKernelGGL(potrf_diag128_kernel, dim3(bt.count), dim3(256), POTRF_LDS, s, A, lda, dinv, d_info, base, bt);
+    hipLaunchKernelGGL(potrf_diag128_kernel, dim3(bt.count), dim3(64 * POTRF_WAVES), POTRF_LDS, s, A, lda, dinv, d_info, base, bt);
 }
 void gpk_trsm_panel128(hipStream_t s, double *X, int M, int ldx, const double *Lkk, int ldl, const double *dinv, double *sumsq,
                        const double *tvec, double *dots, gp_batch bt, double *X2, const double *cs2) {
