@@ -352,7 +352,7 @@ def test_ep_sweeps_vs_oracle(ctx, n, sweeps):
     ep.close()
 
 
-@pytest.mark.parametrize("n,sweeps", [(200, 2), (300, 3), (640, 2), (700, 3)])
+@pytest.mark.parametrize("n,sweeps", [(200, 2), (300, 3), (640, 2), (700, 3), (1600, 2)])   # 1600: far trailing updates on their own stream
 def test_ep_streamed_refactorisation_vs_oracle_and_end_of_sweep_form(ctx, monkeypatch, n, sweeps):
     """The refactorisation of EpParameterEstimator.scala:56-61 run UNDER the site loop (default from n = 1024; forced here)
     against the oracle and against the end-of-sweep form: same L, Sigma, mu, site parameters."""
