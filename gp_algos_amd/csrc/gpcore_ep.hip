@@ -619,9 +619,9 @@ gp_status gp_ep_sweep(gp_ep *ep, int nsweeps, double *tau, double *nu, int *info
     GP_HIP(ctx, hipMemsetAsync(ctx->d_info, 0, sizeof(int), s));
     // GPCORE_EP_OVERLAP=0: every launch of a site block on one stream (the form the overlapped one is tested against)
     const bool overlap = [] { const char *e = getenv("GPCORE_EP_OVERLAP"); return !e || atoi(e) != 0; }();
-    // GPCORE_EP_PIPELINE: 1 / 0 force the streamed refactorisation on / off; default on from np = 1024 (below that a sweep is
-    // a handful of launches and the end-of-sweep form is as fast)
-    const bool pipe = overlap && np >= 2 * GP_NB && [np] { const char *e = getenv("GPCORE_EP_PIPELINE"); return e ? atoi(e) != 0 : np >= 1024; }();
+    // GPCORE_EP_PIPELINE: 1 / 0 force the streamed refactorisation on / off; default on above np = 1024 (sweeps/s with / without
+    // it: n = 1024 552 / 592, n = 2048 382 / 265, n = 4096 162 / 102, n = 8192 29.1 / 27.2)
+    const bool pipe = overlap && np >= 2 * GP_NB && [np] { const char *e = getenv("GPCORE_EP_PIPELINE"); return e ? atoi(e) != 0 : np > 1024; }();
     hipStream_t s2 = ctx->side, s3 = ctx->side2, s4 = ctx->side3;
     const bool far_split = [] { const char *e = getenv("GPCORE_EP_FAR"); return !e || atoi(e) != 0; }();
     const bool sig_small = [] { const char *e = getenv("GPCORE_EP_SIG_K128"); return e && atoi(e) != 0; }();
