@@ -77,6 +77,31 @@ __device__ __forceinline__ double rl64(double v, int lane) {
 __device__ __forceinline__ double dnorm_d(double x) { return exp(-(x * x) / 2.0 - log(sqrt(2.0 * M_PI))); }   // StatsUtils.scala:15
 __device__ __forceinline__ double pnorm_d(double x) { return 0.5 * (1.0 + erf(x / sqrt(2.0))); }              // StatsUtils.scala:17
 
+// A(I-tile, J-tile) -= (S(I-tile, chunk) diag(c)) S(J-tile, chunk)^T for the 16 columns of the chunk starting at column cs0: one
+// 16 x 16 tile of the block's delayed update on the matrix cores, operands and result in LDS (leading dimension LS)
+__device__ __forceinline__ void ep_chunk_tile(double *A, const double *cs, int LS, int I, int J, int cs0, int fr, int fg) {
+    const int ri = 16 * I, rj = 16 * J;
+    double4_t acc;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) acc[rr] = A[(ri + fr) + (rj + fg + 4 * rr) * LS];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const int qq = cs0 + 4 * ks + fg;
+        const double aop = -(cs[qq] * A[(rj + fr) + qq * LS]);
+        const double bop = A[(ri + fr) + qq * LS];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) A[(ri + fr) + (rj + fg + 4 * rr) * LS] = acc[rr];
+}
+
+#ifdef EP_STAMPS   // lab instrumentation (tools/ep_block_stamps.py): cycle stamps of one block's site iterations; never defined in the library build
+__device__ unsigned long long ep_stamps[4 * GP_NB];
+#define EP_STAMP(slot) do { if (i0 == 5 * GP_NB) ep_stamps[(slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define EP_STAMP(slot) do { } while (0)
+#endif
+
 // All site updates of one block of <= 128 consecutive sites (EpParameterEstimator.scala:44-55), on chip, by ONE
 // workgroup.  Inside a block the recurrence only ever touches the block's own rows:
 //   s_t[r] = Sigma0[r, i_t] - sum_{q<t} c_q S[r,q] S[i_t,q]      (r in the block)
@@ -84,7 +109,8 @@ __device__ __forceinline__ double pnorm_d(double x) { return 0.5 * (1.0 + erf(x 
 // so the 128 x 128 diagonal block of Sigma0, the block of S and mu live in LDS for the whole block.  Outputs: the new
 // site/cavity parameters, c, -coef, and Lmat = I + strict_lower(S_blk diag(c)) -- the unit-lower factor with which the
 // full-height columns follow afterwards from ONE row-panel solve,  S = Sigma0[:, blk] Lmat^-T  (trsm_panel128).
-__global__ __launch_bounds__(192) void ep_block_kernel(int n, int np, int i0, int bsz, const double *__restrict__ Sig0,
+constexpr int EP_BLOCK_WAVES = 8;   // waves 0,1: one block row per thread; wave 2: the site chain; wave 3: the site outputs; all: chunk-boundary tiles
+__global__ __launch_bounds__(64 * EP_BLOCK_WAVES) void ep_block_kernel(int n, int np, int i0, int bsz, const double *__restrict__ Sig0,
                                                        const double *__restrict__ mu, const int *__restrict__ y,
                                                        double *__restrict__ tau, double *__restrict__ nu,
                                                        double *__restrict__ cav_tau, double *__restrict__ cav_nu,
@@ -134,6 +160,10 @@ __global__ __launch_bounds__(192) void ep_block_kernel(int n, int np, int i0, in
     const int jtiles = (bsz + 15) >> 4;
     double *cf = sc + 8 + 3 * GP_NB;   // coef of every processed site (rows read it one iteration later)
     double *pub = cf + GP_NB;          // [2][3]: what the scalar lane needs to start a site: P, B, M (see below), by site parity
+    double *ob = pub + 6;              // [2][5]: what the outputs of a site are made of (1/sii, tau_old, sg, mi, cavity nu), by site parity
+    double *ctb = ob + 10;             // cavity tau and nu of every processed site.  NOTHING is stored to global memory inside the site
+    double *cnb = ctb + GP_NB;         //   loop: a barrier waits for the wave's outstanding stores, i.e. every site would pay an
+                                       //   L2 round trip; the new site parameters replace the staged old ones in tb / nb
     // One barrier per site.  The scalar lane of wave 2 runs the serial chain of site t (erf, exp, reciprocals) while the row
     // threads, one site BEHIND it, (i) finish column t with site t-1's result and update the mean, (ii) build the part of
     // column t+1 that does not depend on site t (q < t, at most 14 terms of the current 16-site chunk) and (iii) row thread
@@ -143,6 +173,8 @@ __global__ __launch_bounds__(192) void ep_block_kernel(int n, int np, int i0, in
     if (tid == 0) { pub[0] = A[0]; pub[1] = 0.0; pub[2] = mb[0]; }
     __syncthreads();
     double part = 0.0, c_prev = 0.0, coef_prev = 0.0;
+    double4_t dacc = {0.0, 0.0, 0.0, 0.0};   // waves 4-7: the deferred tile in flight
+    int dcs0 = -1, dJ0 = 8;   // chunk whose update of the later tile columns is still being applied (waves 4-7), first of those columns
     for (int t = 0; t < bsz; ++t) {
         const int cs0 = t & ~15;
         const bool first = (t & 15) == 0;                    // first site of a chunk: its column has no pending term
@@ -150,36 +182,75 @@ __global__ __launch_bounds__(192) void ep_block_kernel(int n, int np, int i0, in
         const bool build_next = (t + 1 < bsz) && !boundary;  // row threads prepare column t+1 in this iteration
         if (!rowthread) {
             if (tid == GP_NB) {
-                const int i = i0 + t;
+                EP_STAMP(4 * t + 0);
                 const double *pb = pub + 3 * (t & 1);
                 const double Bv = pb[1];
                 const double sii = fma(-c_prev * Bv, Bv, pb[0]);
                 const double mui = fma(Bv, coef_prev, pb[2]);
-                const double to = tb[t], no = nb[t];
-                const double rs = rcp_nr(sii);
-                const double tc = rs - to;                              // cavity tau  :45
-                const double nc = mui * rs - no;                        // cavity nu   :46
-                const double cvr = rcp_nr(tc);                          // cavity variance 1/tau
-                const double cm = nc * cvr;                             // cavity mean
-                const double yi = yb[t];
-                const double rt = rsqrt(1.0 + cvr);                     // 1/sqrt(1 + sigma^2)
+                const double to = tb[t], no = nb[t], yi = yb[t];
+                // The serial chain carries the tilted moments only.  With sigma^2 = sii, the new marginal variance sg and mean mi:
+                //   c = 1/(1/dtau + sii) = (sii - sg)/sii^2,   coef = dnu - c (mui + dnu sii) = (mi - mui)/sii
+                // (substitute dtau = 1/sg - 1/sii, dnu = mi/sg - mui/sii): no reciprocal of sg, of dtau or of 1 + dtau sii on
+                // the chain, and the cavity variance 1/(1/sii - to) = sii/(1 - to sii) is ONE reciprocal deep instead of two.
+                const double rs = rcp_nr(sii);                              // 1/sii, beside the cavity variance
+                const double cvr = sii * rcp_nr(fma(-to, sii, 1.0));        // cavity variance
+                const double nc = fma(mui, rs, -no);                        // cavity nu   :46
+                const double cm = nc * cvr;                                 // cavity mean
+                const double rt = rsqrt(1.0 + cvr);                         // 1/sqrt(1 + sigma^2)
                 const double z = (yi * cm) * rt;
-                const double ratio = dnorm_d(z) * rcp_nr(pnorm_d(z));    // phi(z)/Phi(z)
+                const double Phi = 0.5 * (1.0 + erf(z * 0.70710678118654752440));
+                const double ratio = dnorm_d(z) * rcp_nr(Phi);              // phi(z)/Phi(z)
                 const double mi_hat = cm + (yi * cvr) * (ratio * rt);
                 const double sg_hat = cvr - (cvr * cvr) * (ratio * (z + ratio)) * (rt * rt);
-                const double isg = rcp_nr(sg_hat);
-                const double dtau = isg - tc - to;                      // :49
-                const double tn = to + dtau;                            // :50
-                const double nn = mi_hat * isg - nc;                    // :51
-                const double c = dtau * rcp_nr(fma(dtau, sii, 1.0));     // 1/(1/dtau + sii), finite at dtau = 0  :53
-                const double dnu = nn - no;
-                const double coef = dnu - c * (mui + dnu * sii);
+                const double c = (sii - sg_hat) * (rs * rs);                // :53
+                const double coef = (mi_hat - mui) * rs;
                 cs[t] = c;
                 cf[t] = coef;
                 c_prev = c, coef_prev = coef;
-                tau[i] = tn; nu[i] = nn; cav_tau[i] = tc; cav_nu[i] = nc;
-                cvec[t] = c;
-                ncoef[t] = coef;
+                double *o = ob + 5 * (t & 1);
+                o[0] = rs, o[1] = to, o[2] = sg_hat, o[3] = mi_hat, o[4] = nc;
+                EP_STAMP(4 * t + 1);
+            } else if (wave >= 4) {
+                // deferred tiles of the chunk closed at the last boundary, HALF a tile per site iteration (a whole one takes longer
+                // than the site chain and would hold up the barrier): tile k = 4 (pair of sites within the chunk) + (wave - 4) of the
+                // enumeration J = dJ0 .. jtiles-1, I = J .. 7; first half = accumulator + k-steps 0,1, second half = k-steps 2,3 + store
+                if (dcs0 >= 0) {
+                    const int it = t - (dcs0 + 16);
+                    int k = 4 * (it >> 1) + (wave - 4), I = -1, J = dJ0;
+                    for (; J < jtiles; ++J) {
+                        if (k < 8 - J) { I = J + k; break; }
+                        k -= 8 - J;
+                    }
+                    if (I >= 0) {
+                        const int ri = 16 * I, rj = 16 * J, ks0 = 2 * (it & 1);
+                        if (ks0 == 0) {
+#pragma unroll
+                            for (int rr = 0; rr < 4; ++rr) dacc[rr] = A[(ri + fr) + (rj + fg + 4 * rr) * LS];
+                        }
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks) {
+                            const int qq = dcs0 + 4 * (ks0 + ks) + fg;
+                            const double aop = -(cs[qq] * A[(rj + fr) + qq * LS]);
+                            const double bop = A[(ri + fr) + qq * LS];
+                            dacc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, dacc, 0, 0, 0);
+                        }
+                        if (ks0 == 2) {
+#pragma unroll
+                            for (int rr = 0; rr < 4; ++rr) A[(ri + fr) + (rj + fg + 4 * rr) * LS] = dacc[rr];
+                        }
+                    }
+                }
+            } else if (tid == GP_NB + 64 && t > 0) {
+                // wave 3: the outputs of the PREVIOUS site (:45-51 as written).  Nothing in the recurrence waits for them, so they
+                // are computed beside the chain of the current site, from what the chain left in LDS before the last barrier.
+                const double *o = ob + 5 * ((t - 1) & 1);
+                const double tc = o[0] - o[1];                              // cavity tau  :45
+                const double isg = rcp_nr(o[2]);
+                const double dtau = isg - tc - o[1];                        // :49
+                tb[t - 1] = o[1] + dtau;                                    // :50
+                nb[t - 1] = o[3] * isg - o[4];                              // :51
+                ctb[t - 1] = tc;
+                cnb[t - 1] = o[4];
             }
         } else {
             if (!first && r >= t) {     // site t-1's result: mean, and column t becomes final
@@ -216,30 +287,19 @@ __global__ __launch_bounds__(192) void ep_block_kernel(int n, int np, int i0, in
                 }
             }
         }
+        if (tid == GP_NB - 1) EP_STAMP(4 * t + 2);
         __syncthreads();
+        if (tid == GP_NB) EP_STAMP(4 * t + 3);
         if (boundary && t + 1 < bsz) {
             // the chunk is complete (column t became final above, c_t is known): mean for site t, then the chunk's 16 columns are
             // applied to every later column of the block on the matrix cores -- tiles (I, J), jc <= J <= I < 8, J < jtiles
             if (rowthread && r > t) mb[r] = fma(Sb[r + t * LS], cf[t], mb[r]);
+            // Only tile column jc -- the next chunk's own columns -- is needed now: its 8 - jc tiles go one to a wave.  The tile
+            // columns to the right of it are not read before THEIR chunk starts, so waves 4-7 apply this chunk to them one tile
+            // per site iteration while the next chunk's sites run (at most 21 tiles against 4 x 16 slots).
             const int jc = (t + 1) >> 4;
-            int q = wave;
-            for (int J = jc; J < jtiles; ++J)
-                for (int I = J; I < 8; ++I, q = (q == 0 ? 2 : q - 1)) {
-                    if (q != 0) continue;
-                    const int ri = 16 * I, rj = 16 * J;
-                    double4_t acc;
-#pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) acc[rr] = A[(ri + fr) + (rj + fg + 4 * rr) * LS];
-#pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) {
-                        const int qq = cs0 + 4 * ks + fg;
-                        const double aop = -(cs[qq] * Sb[(rj + fr) + qq * LS]);
-                        const double bop = Sb[(ri + fr) + qq * LS];
-                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, acc, 0, 0, 0);
-                    }
-#pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) A[(ri + fr) + (rj + fg + 4 * rr) * LS] = acc[rr];
-                }
+            if (jc + wave < 8 && jc < jtiles) ep_chunk_tile(A, cs, LS, jc + wave, jc, cs0, fr, fg);
+            dcs0 = cs0, dJ0 = jc + 1;
             __syncthreads();
             if (tid == t + 1) {   // site t+1 starts a chunk: nothing pending on its column
                 double *pb = pub + 3 * ((t + 1) & 1);
@@ -249,6 +309,25 @@ __global__ __launch_bounds__(192) void ep_block_kernel(int n, int np, int i0, in
             }
             __syncthreads();
         }
+    }
+    if (tid == GP_NB + 64 && bsz > 0) {   // outputs of the last site (the loop ended on a barrier)
+        const double *o = ob + 5 * ((bsz - 1) & 1);
+        const double tc = o[0] - o[1];
+        const double isg = rcp_nr(o[2]);
+        const double dtau = isg - tc - o[1];
+        tb[bsz - 1] = o[1] + dtau;
+        nb[bsz - 1] = o[3] * isg - o[4];
+        ctb[bsz - 1] = tc;
+        cnb[bsz - 1] = o[4];
+    }
+    __syncthreads();
+    if (rowthread && r < bsz) {   // the block's results, in one go
+        tau[i0 + r] = tb[r];
+        nu[i0 + r] = nb[r];
+        cav_tau[i0 + r] = ctb[r];
+        cav_nu[i0 + r] = cnb[r];
+        cvec[r] = cs[r];
+        ncoef[r] = cf[r];
     }
     // column bsz-1 became final in the last iteration unless the block has a single site or ends on a chunk's first site
     if (rowthread) {
@@ -260,7 +339,7 @@ __global__ __launch_bounds__(192) void ep_block_kernel(int n, int np, int i0, in
     // Ldinv + 256 q, element (c, k) at c + 16 k): forward substitution against the identity, here instead of in a launch of
     // its own between the block kernel and the solve.  Wave 2 (idle while the row threads write Lmat) takes four tiles at a
     // time, 16 lanes per tile, column owner = lane & 15; L(rr, k) comes back as an LDS broadcast within each 16-lane group.
-    if (!rowthread) {
+    if (wave == 2) {
 #pragma unroll 1
         for (int half = 0; half < 2; ++half) {
             const int c0 = 16 * (4 * half + fg);
@@ -435,7 +514,7 @@ __global__ __launch_bounds__(1024) void ep_lml_kernel(int n, int ldl, const doub
     if (threadIdx.x == 0) out[0] = red[0];
 }
 
-constexpr int EP_BLOCK_LDS = (GP_NB * (GP_NB + 1) + 6 * GP_NB + 16) * (int)sizeof(double);
+constexpr int EP_BLOCK_LDS = (GP_NB * (GP_NB + 1) + 8 * GP_NB + 32) * (int)sizeof(double);
 inline dim3 g1(int n) { return dim3((n + 255) / 256); }
 
 // out[i] = sum_j A(i,j) x[j] for rows i in [lo, lo + m) of a SYMMETRIC n x n matrix of which only the lower triangle is stored
@@ -672,7 +751,7 @@ gp_status gp_ep_sweep(gp_ep *ep, int nsweeps, double *tau, double *nu, int *info
             const int par = b & 1;
             double *Lmat = ep->blk + (size_t)par * (GP_NB * GP_NB + 8 * 256), *bdinv = Lmat + GP_NB * GP_NB;
             double *cvec = ep->cvec + (size_t)par * 2 * GP_NB, *ncoef = cvec + GP_NB;   // c and coef of every site of the block
-            hipLaunchKernelGGL(ep_block_kernel, dim3(1), dim3(192), EP_BLOCK_LDS, s, n, np, i0, bsz, ep->Sig, ep->mu(), ep->y,
+            hipLaunchKernelGGL(ep_block_kernel, dim3(1), dim3(64 * EP_BLOCK_WAVES), EP_BLOCK_LDS, s, n, np, i0, bsz, ep->Sig, ep->mu(), ep->y,
                                ep->tau(), ep->nu(), ep->cav_tau(), ep->cav_nu(), cvec, ncoef, Lmat, bdinv);
             hipEvent_t ev_fac = ep->ev[4 * b], ev_rows = ep->ev[4 * b + 1], ev_side = ep->ev[4 * b + 2], ev_vt = ep->ev[4 * b + 3];
             if (overlap) GP_HIP(ctx, hipEventRecord(ev_fac, s));
@@ -1003,6 +1082,12 @@ static gp_status ep_eval_batched(gp_ctx *ctx, const double *X, int n, int d, int
         }
     return GP_OK;
 }
+
+#ifdef EP_STAMPS
+gp_status gp_debug_ep_stamps(unsigned long long *out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(ep_stamps), sizeof(unsigned long long) * 4 * GP_NB) == hipSuccess ? GP_OK : GP_EHIP;
+}
+#endif
 
 void gp_ep_destroy(gp_ep *ep) {
     if (!ep) return;
