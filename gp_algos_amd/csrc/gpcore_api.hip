@@ -403,8 +403,7 @@ void gpi_chol_blocked(gp_ctx *ctx, double *A, int np, int lda, double *dinv, int
 
 // Step k0 of chol_blocked (single problem, GP_OUTER-wide outer panels, no look-ahead) on stream s.  Calling it for
 // k0 = 0, 128, ..., np - 128 in order IS the factorisation; the caller may change columns >= k0 between steps (the EP sweep
-// scales block k0's rows and columns when its site precisions become final).  Not profiled per class: the launches are not on
-// the context's stream.  `solved` (optional) is recorded when block column k0 of the factor (and of the rows riding along) is final.
+// scales block k0's rows and columns when its site precisions become final).  `solved` (optional) is recorded when block column k0 of the factor (and of the rows riding along) is final.
 // With a `far` stream (and `solved`, `far_done`) the step that closes an outer panel only updates the NEXT outer panel's columns on s
 // and leaves everything to the right of it to `far`, which starts at `solved` and records `far_done`; the closing step of the next
 // outer panel waits for that event before it touches those columns (the look-ahead of chol_blocked, one step at a time).
@@ -422,8 +421,10 @@ void gpi_chol_panel_step(gp_ctx *ctx, hipStream_t s, double *A, int np, int lda,
     if (r <= 0) return;
     const int c1 = K0 + wcols, wc = c1 - (k0 + GP_NB);
     if (wc > 0) {
+        gp_prof_begin(ctx, GP_PROF_PANEL_UPD, s);
         if (small_panel_update()) gpk_gemm_k128_sub(s, r, wc, A21, lda, A21, lda, A21 + (size_t)GP_NB * lda, lda, 1);
         else gpk_gemm_nt(s, r, wc, GP_NB, -1.0, A21, lda, A21, lda, 1.0, A21 + (size_t)GP_NB * lda, lda, 1);
+        gp_prof_end(ctx, GP_PROF_PANEL_UPD, trapezoid_flops(r, wc, GP_NB), s);
         return;
     }
     const int R = np - c1;
@@ -436,18 +437,22 @@ void gpi_chol_panel_step(gp_ctx *ctx, hipStream_t s, double *A, int np, int lda,
         const int c2 = c1 + near;
         const double *P2 = A + (size_t)c2 + (size_t)K0 * lda;
         const double tiles = trapezoid_flops(rows - c2, np - c2, wcols) / (2.0 * GP_NB * GP_NB * wcols);
+        gp_prof_begin(ctx, GP_PROF_SYRK, far);
         if (tiles < small_update_tiles() && small_panel_update())
             gpk_gemm_k128_sub(far, rows - c2, np - c2, P2, lda, P2, lda, A + (size_t)c2 + (size_t)c2 * lda, lda, 1, wcols);
         else
             gpk_gemm_nt(far, rows - c2, np - c2, wcols, -1.0, P2, lda, P2, lda, 1.0, A + (size_t)c2 + (size_t)c2 * lda, lda, 1);
+        gp_prof_end(ctx, GP_PROF_SYRK, trapezoid_flops(rows - c2, np - c2, wcols), far);
     }
     if (split) (void)hipEventRecord(far_done, far);
     const double *P = A + (size_t)c1 + (size_t)K0 * lda;
     const double tiles128 = trapezoid_flops(rows - c1, near, wcols) / (2.0 * GP_NB * GP_NB * wcols);
+    gp_prof_begin(ctx, GP_PROF_SYRK, s);
     if (tiles128 < small_update_tiles() && small_panel_update())
         gpk_gemm_k128_sub(s, rows - c1, near, P, lda, P, lda, A + (size_t)c1 + (size_t)c1 * lda, lda, 1, wcols);
     else
         gpk_gemm_nt(s, rows - c1, near, wcols, -1.0, P, lda, P, lda, 1.0, A + (size_t)c1 + (size_t)c1 * lda, lda, 1);
+    gp_prof_end(ctx, GP_PROF_SYRK, trapezoid_flops(rows - c1, near, wcols), s);
 }
 void gpi_solve_rows_lower(gp_ctx *ctx, double *Vt, int mp, const double *L, int np, int ldl, const double *dinv, double *sumsq,
                           const double *tvec, double *dots) { solve_rows_lower(ctx, Vt, mp, L, np, ldl, dinv, sumsq, tvec, dots); }

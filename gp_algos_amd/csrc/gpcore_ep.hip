@@ -13,6 +13,7 @@
 // refactorisation (L = chol(I + S^1/2 K S^1/2), V = L \ S^1/2 K, Sigma = K - V^T V, mu = Sigma nu) reuses
 // the blocked Cholesky, the row-panel solve and the MFMA syrk of the regression path.
 #include "gpcore_internal.h"
+#include "dpp_tile.h"
 
 #include <algorithm>
 #include <atomic>
@@ -337,26 +338,20 @@ __global__ __launch_bounds__(64 * EP_BLOCK_WAVES) void ep_block_kernel(int n, in
     }
     // inverses of Lmat's eight 16 x 16 diagonal tiles (unit lower), the form the row-panel solve consumes (tile q at
     // Ldinv + 256 q, element (c, k) at c + 16 k): forward substitution against the identity, here instead of in a launch of
-    // its own between the block kernel and the solve.  Wave 2 (idle while the row threads write Lmat) takes four tiles at a
-    // time, 16 lanes per tile, column owner = lane & 15; L(rr, k) comes back as an LDS broadcast within each 16-lane group.
-    if (wave == 2) {
-#pragma unroll 1
-        for (int half = 0; half < 2; ++half) {
-            const int c0 = 16 * (4 * half + fg);
-            double x[16];
+    // its own between the block kernel and the solve.  Waves 2 and 3 (idle while the row threads write Lmat) take four tiles each.
+    if (wave == 2 || wave == 3) {
+        // tiles 4 (wave - 2) + fg: the four 16-lane rows of a wave take one tile each; row owner = column owner = lane & 15, the
+        // tile's rows in registers, every cross-lane operand a DPP row broadcast (dpp_tile.h) -- no LDS traffic, no chain of loads
+        const int c0 = 16 * (4 * (wave - 2) + fg);
+        double row[16], sv[16], x[16];
 #pragma unroll
-            for (int rr = 0; rr < 16; ++rr) {
-                double sacc = (rr == fr) ? 1.0 : 0.0;
-#pragma unroll
-                for (int k = 0; k < rr; ++k) {
-                    const double lrk = (c0 + k < bsz) ? Sb[(c0 + rr) + (c0 + k) * LS] * cs[c0 + k] : 0.0;
-                    sacc = fma(-lrk, x[k], sacc);
-                }
-                x[rr] = sacc;   // unit diagonal
-            }
-#pragma unroll
-            for (int rr = 0; rr < 16; ++rr) Ldinv[(c0 / 16) * 256 + rr + 16 * fr] = x[rr];
+        for (int k = 0; k < 16; ++k) {
+            row[k] = (c0 + k < bsz) ? Sb[(c0 + fr) + (c0 + k) * LS] * cs[c0 + k] : 0.0;   // only k < fr is used
+            sv[k] = (k == fr) ? 1.0 : 0.0;
         }
+        tile_unit_inverse<0>(row, sv, x);
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) Ldinv[(c0 / 16) * 256 + rr + 16 * fr] = x[rr];
     }
 }
 
@@ -767,8 +762,10 @@ gp_status gp_ep_sweep(gp_ep *ep, int nsweeps, double *tau, double *nu, int *info
                     GP_HIP(ctx, hipStreamWaitEvent(s4, ev_vt, 0));
                     const int kw = i0 + GP_NB - pend0;
                     const double *Vb = ep->L + np + (size_t)pend0 * ep->ldl;
+                    gp_prof_begin(ctx, GP_PROF_SYRK, s4);
                     if (pend0 > 0 && sig_small) gpk_gemm_k128_sub(s4, np, np, Vb, ep->ldl, Vb, ep->ldl, ep->Sig2, np, 1, kw);
                     else gpk_gemm_nt(s4, np, np, kw, -1.0, Vb, ep->ldl, Vb, ep->ldl, 1.0, ep->Sig2, np, 1, 0, gp_batch(), pend0 == 0 ? ep->K : nullptr, np);
+                    gp_prof_end(ctx, GP_PROF_SYRK, (double)np * ((double)np + GP_NB) * kw, s4);
                     pend0 = i0 + GP_NB;
                 }
             }

@@ -15,6 +15,7 @@
 // backSolve (MatrixUtils.scala:17-35,115-133).  Only the 16x16 tile inverses are explicit inverses;
 // everything larger is substitution, so the backward error stays at the substitution level.
 #include "gpcore_internal.h"
+#include "dpp_tile.h"
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 typedef double double2_t __attribute__((ext_vector_type(2)));
@@ -40,41 +41,6 @@ __device__ __forceinline__ double rl64(double v, int lane) {
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 
-// d -= a(lane C of this lane's 16-lane row) * b: ONE DPP instruction (row_newbcast on a 64-bit VALU op) where the portable form
-// costs two v_readlane + an FMA.  A DPP read needs 2 wait states after a VALU write of the same VGPR and the hazard recogniser
-// does not look inside inline asm: the FIRST use of a freshly written `a` goes through fnma_bcast_first, which carries the s_nop
-// and passes `a` through as an output, so that every later use depends on it and cannot be scheduled ahead of it.
-template <int C>
-__device__ __forceinline__ void fnma_bcast_first(double &d, double &a, double b) {
-    asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(d), "+v"(a) : "v"(b), "n"(C));
-}
-template <int C>
-__device__ __forceinline__ void fnma_bcast(double &d, double a, double b) {
-    asm("v_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(d) : "v"(a), "v"(b), "n"(C));
-}
-// lane C of this lane's 16-lane row, copied to every lane of the row
-template <int C>
-__device__ __forceinline__ double bcast_row(double a) {
-    double d;
-    asm("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(d) : "v"(a), "n"(C));
-    return d;
-}
-// trailing columns of step J of the 16 x 16 tile factorisation: row[c] -= row[J] * L(c, J), c = C .. 15
-template <int J, int C>
-__device__ __forceinline__ void tile_update_cols(double (&row)[16], double lj) {
-    if constexpr (C < 16) {
-        fnma_bcast<C>(row[C], lj, lj);
-        tile_update_cols<J, C + 1>(row, lj);
-    }
-}
-// step J of the inverse, right-looking: s[rr] -= L(rr, J) x[J], rr = RR .. 15, with L(rr, J) = row[J] of lane rr
-template <int J, int RR>
-__device__ __forceinline__ void tile_inv_update(double (&s)[16], double lj, double xj) {
-    if constexpr (RR < 16) {
-        fnma_bcast<RR>(s[RR], lj, xj);
-        tile_inv_update<J, RR + 1>(s, lj, xj);
-    }
-}
 // Column J of the 16 x 16 tile Cholesky (row owner = lane & 15, replicated in the four 16-lane rows of the wave) together
 // with step J of the tile inverse X = L^-1 (column owner = lane & 15).  Both are chains of DEPENDENT fp64 operations
 // (~16 cycles each on this hardware, measured: the factorisation alone 219 cycles per column, the inverse as much again when it
