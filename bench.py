@@ -317,7 +317,7 @@ def run_secondary(args):
     gdist.barrier()
 
 
-PMC_SUMMARY = "r02_b_pmc_c2_summary.json"
+PMC_SUMMARY = "r02_c_pmc_c2_summary.json"
 DOMINANT_KERNEL = "gemm_fused_kernel<0,0,1,8>"
 
 
