@@ -585,7 +585,15 @@ gp_status ep_refactor(gp_ep *ep) {
     gp_prof_end(ctx, GP_PROF_SYRK, 2.0 * GP_NB * GP_NB * np * ((double)(np / GP_NB) * (c1 / GP_NB) - (double)(c1 / GP_NB) * (c1 / GP_NB - 1) / 2.0));
     double *partial;   // rows of the two parts are disjoint, so both streams may use it at once
     GP_TRY(gpi_ws_get(ctx, WS_PARTIAL, sizeof(double) * (size_t)(SYMV_CHUNKS + 1) * np, &partial));
-    ep_symv_lower(s, ep->Sig, np, np, ep->nu(), partial, ep->mu(), 0, c1);
+    // the second part's mu = Sigma nu runs under the NEXT sweep's first block kernels, which already write new site parameters:
+    // it multiplies a snapshot of nu taken here (found by tools/ep_identity_check.py: several sweeps in one call drifted from
+    // one sweep per call by 1e-4 .. 1e-2 relative at n = 2500 / 3000 before this copy existed)
+    const double *nu_now = ep->nu();
+    if (split) {
+        GP_HIP(ctx, hipMemcpyAsync(ep->tmp2(), ep->nu(), sizeof(double) * (size_t)np, hipMemcpyDeviceToDevice, s));
+        nu_now = ep->tmp2();
+    }
+    ep_symv_lower(s, ep->Sig, np, np, nu_now, partial, ep->mu(), 0, c1);
     if (split) {
         const int r = np - c1;
         // the second part starts when the first is done: started together, the two launches share the chip and the columns the
@@ -596,7 +604,7 @@ gp_status ep_refactor(gp_ep *ep) {
         gpk_gemm_nt(s2, r, r, np, -1.0, Vt + c1, ldl, Vt + c1, ldl, 1.0, ep->Sig + (size_t)c1 + (size_t)c1 * np, np, 1, 0, gp_batch(),
                     ep->K + (size_t)c1 + (size_t)c1 * np, np);
         gp_prof_end(ctx, GP_PROF_SYRK, 2.0 * GP_NB * GP_NB * np * ((double)(r / GP_NB) * (r / GP_NB + 1) / 2.0), s2);
-        ep_symv_lower(s2, ep->Sig, np, np, ep->nu(), partial, ep->mu(), c1, r);   // rows >= 512 of mu also read the first 512 columns
+        ep_symv_lower(s2, ep->Sig, np, np, nu_now, partial, ep->mu(), c1, r);   // rows >= 512 of mu also read the first 512 columns
         GP_HIP(ctx, hipEventRecord(ep->ev_partb, s2));
         ep->side_pending = true;
     }

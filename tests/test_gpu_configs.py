@@ -164,6 +164,38 @@ def test_c4_full_size_50_sweeps(ctx):
     ep.close()
 
 
+def test_ep_streamed_refactorisation_at_a_ragged_size(ctx, monkeypatch):
+    """n = 3000 (np = 3072: six outer panels, the last site block partly padding): the refactorisation streamed under the site loop
+    (default at this size) against the end-of-sweep form and against the identities of EpParameterEstimator.scala:56-61."""
+    from gp_algos_amd import _lib as L
+    from gp_algos_amd.core import EpClassifierState
+    n = 3000
+    p = synth.config_c4(n, 8)
+    K = ctx.gram_rbf(p["X"], p["theta"])
+    K[np.diag_indices_from(K)] += 1e-6
+    got = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("GPCORE_EP_PIPELINE", mode)
+        ep = EpClassifierState(ctx, K, p["y"])
+        tau, nu = ep.sweep(6)
+        got[mode] = dict(tau=tau, nu=nu, Sig=ep.get(L.GP_EP_GET_SIGMA), mu=ep.get(L.GP_EP_GET_MU), L=ep.get(L.GP_EP_GET_L),
+                         lml=ep.lml(False))
+        ep.close()
+    g = got["1"]
+    assert np.all(np.isfinite(g["tau"])) and np.all(g["tau"] > 0)
+    V = np.random.default_rng(2).standard_normal((n, 3))
+    KV = K @ V
+    assert np.linalg.norm(g["Sig"] @ (V + g["tau"][:, None] * KV) - KV) / np.linalg.norm(KV) <= 1e-9
+    assert np.max(np.abs(g["Sig"] @ g["nu"] - g["mu"])) <= 1e-9 * np.max(np.abs(g["mu"]))
+    st = np.sqrt(g["tau"])
+    BV = V + st[:, None] * (K @ (st[:, None] * V))
+    assert np.linalg.norm(g["L"] @ (g["L"].T @ V) - BV) / np.linalg.norm(BV) <= 1e-12
+    assert np.all(np.triu(g["L"], 1) == 0.0) and np.array_equal(g["Sig"], g["Sig"].T)
+    for key in ("tau", "nu", "mu", "Sig", "L"):
+        assert np.max(np.abs(g[key] - got["0"][key])) <= 1e-9 * np.max(np.abs(got["0"][key])), key
+    assert abs(g["lml"] - got["0"]["lml"]) <= 1e-9 * abs(got["0"]["lml"])
+
+
 # ---- C5 at full size -------------------------------------------------------------------------------------------------------
 def test_c5_full_size_fit_and_large_batch_variances(ctx):
     """Config C5 per GPU: n = 32768, d = 8 fit (8.6 GB factor, outer panel 1024) and one 131 072-point posterior batch."""
