@@ -196,6 +196,32 @@ def test_ep_streamed_refactorisation_at_a_ragged_size(ctx, monkeypatch):
     assert abs(g["lml"] - got["0"]["lml"]) <= 1e-9 * abs(got["0"]["lml"])
 
 
+def test_cholesky_lookahead_on_the_side_stream_is_the_same_factorisation(ctx):
+    """The far trailing updates on the CU-masked side stream (default for single factorisations with >= 6144 rows, i.e. the C2 fit)
+    against the one-stream form: the same tiles by the same kernels, so L, alpha and the LML must be IDENTICAL -- also when
+    several refits are queued back to back -- and L L^T = K."""
+    from gp_algos_amd import _lib as L
+    from gp_algos_amd.core import RegressionModel
+    n, d = 6400, 4
+    p = synth.regression(n, d, 0, 51, 52, 0, np.array([1.3, 1.0, 1.4, 0.8, 1.2, 0.15]))
+    lib = ctx._lib
+    got = {}
+    for la in (1, 0):
+        ctx.check(lib.gp_ctx_set_lookahead(ctx.h, la))
+        m = RegressionModel(ctx, p["X"], p["y"], p["theta"])
+        for _ in range(3):                                          # refits queued without a host sync in between
+            ctx.check(lib.gp_model_refit_dev(m.h, L.dptr(L.f64(p["theta"])), float("nan")))
+        got[la] = (m.L(), m.alpha(), m.lml())
+        m.close()
+    ctx.check(lib.gp_ctx_set_lookahead(ctx.h, -1))
+    assert np.array_equal(got[1][0], got[0][0]) and np.array_equal(got[1][1], got[0][1]) and got[1][2] == got[0][2]
+    Lf = got[1][0]
+    K = orc.gram_sym(p["X"], p["theta"])
+    V = np.random.default_rng(3).standard_normal((n, 3))
+    assert np.linalg.norm(Lf @ (Lf.T @ V) - K @ V) / np.linalg.norm(K @ V) <= 1e-13
+    assert np.all(np.triu(Lf, 1) == 0.0)
+
+
 # ---- C5 at full size -------------------------------------------------------------------------------------------------------
 def test_c5_full_size_fit_and_large_batch_variances(ctx):
     """Config C5 per GPU: n = 32768, d = 8 fit (8.6 GB factor, outer panel 1024) and one 131 072-point posterior batch."""
