@@ -532,16 +532,19 @@ gp_status gp_ctx_create(int device, void *stream, gp_ctx **out) {
         if (const char *rc = getenv("GPCORE_RESERVED_CUS_EP")) reserved_ep = atoi(rc);
         // side2 carries the factorisation chain: its workgroups are short-lived (quarter-size tiles) but its single-workgroup
         // diagonal kernel needs a whole CU's LDS, which it only finds quickly on the CUs the masked streams leave alone -- so side2
-        // itself is NOT masked (GPCORE_EP_CHAIN_MASK=1 masks it like side3)
-        const bool chain_mask = [] { const char *m = getenv("GPCORE_EP_CHAIN_MASK"); return m && atoi(m) != 0; }();
+        // itself is NOT masked.  (GPCORE_EP_CHAIN_MASK=k keeps k CUs free of side2 as well; measured with the 25 us diagonal kernel,
+        // k = 0 / 8 / 16 / 24 / 32: 163.5 / 162.7 / 163.2 / 162.3 / 164.3 sweeps/s at n = 4096 -- no effect, so the slow-down of the
+        // site loop's small kernels while the other streams' GEMMs run is not a matter of finding a free CU.)
+        const int chain_reserved = [] { const char *m = getenv("GPCORE_EP_CHAIN_MASK"); return m ? atoi(m) : 0; }();
         for (hipStream_t *sp : {&ctx->side2, &ctx->side3}) {
             if (e != hipSuccess) break;
             em = hipErrorInvalidValue;
-            if (reserved_ep > 0 && ctx->num_cu >= 64 && (sp != &ctx->side2 || chain_mask)) {
+            const int rsv = (sp == &ctx->side2) ? chain_reserved : reserved_ep;
+            if (rsv > 0 && ctx->num_cu >= 64) {
                 const int words = (ctx->num_cu + 31) / 32;
                 std::vector<uint32_t> mask(words, 0xFFFFFFFFu);
                 if (ctx->num_cu % 32) mask[words - 1] = (1u << (ctx->num_cu % 32)) - 1u;
-                for (int i = 0; i < reserved_ep && i < ctx->num_cu; ++i) mask[i / 32] &= ~(1u << (i % 32));
+                for (int i = 0; i < rsv && i < ctx->num_cu; ++i) mask[i / 32] &= ~(1u << (i % 32));
                 em = hipExtStreamCreateWithCUMask(sp, (uint32_t)words, mask.data());
             }
             if (em != hipSuccess) { (void)hipGetLastError(); e = hipStreamCreateWithFlags(sp, hipStreamNonBlocking); }
