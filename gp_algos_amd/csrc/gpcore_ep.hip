@@ -705,6 +705,10 @@ gp_status gp_ep_sweep(gp_ep *ep, int nsweeps, double *tau, double *nu, int *info
     // it: n = 1024 552 / 592, n = 2048 382 / 265, n = 4096 162 / 102, n = 8192 29.1 / 27.2)
     const bool pipe = overlap && np >= 2 * GP_NB && [np] { const char *e = getenv("GPCORE_EP_PIPELINE"); return e ? atoi(e) != 0 : np > 1024; }();
     hipStream_t s2 = ctx->side, s3 = ctx->side2, s4 = ctx->side3;
+    // The link between two block kernels as ONE launch (gpk_ep_link) or as panel solve + tile update on 2 + 36 workgroups: alone the two
+    // launches are faster (the single workgroup is bound by one CU's matrix pipe: n = 4096 end-of-sweep form 106.9 vs 103.3 sweeps/s),
+    // under the streamed refactorisation's GEMMs the fused one is (167.4 vs 163.9) -- so it follows `pipe` (GPCORE_EP_LINK overrides)
+    const bool fused_link = [pipe] { const char *e = getenv("GPCORE_EP_LINK"); return e ? atoi(e) != 0 : pipe; }();
     const bool far_split = [] { const char *e = getenv("GPCORE_EP_FAR"); return !e || atoi(e) != 0; }();
     const bool sig_small = [] { const char *e = getenv("GPCORE_EP_SIG_K128"); return e && atoi(e) != 0; }();
     const int nblk = np / GP_NB;
@@ -799,8 +803,11 @@ gp_status gp_ep_sweep(gp_ep *ep, int nsweeps, double *tau, double *nu, int *info
             }
             // main stream: the 128 rows of block b+1 -- they read Sigma entries the side stream's update of block b-1 wrote
             if (b > 0) GP_HIP(ctx, hipStreamWaitEvent(s, ep->ev[4 * (b - 1) + 2], 0));
-            gpk_trsm_panel128(s, St, GP_NB, np, Lmat, GP_NB, bdinv, nullptr, ncoef, ep->mu() + r0, gp_batch(), Sct, cvec);
-            hipLaunchKernelGGL(ep_diag_update_kernel, dim3(36), dim3(64), 0, s, Ctr, np, Sct, St, np);
+            if (fused_link) gpk_ep_link(s, St, np, Lmat, bdinv, ncoef, ep->mu() + r0, Sct, cvec, Ctr, np);
+            else {
+                gpk_trsm_panel128(s, St, GP_NB, np, Lmat, GP_NB, bdinv, nullptr, ncoef, ep->mu() + r0, gp_batch(), Sct, cvec);
+                hipLaunchKernelGGL(ep_diag_update_kernel, dim3(36), dim3(64), 0, s, Ctr, np, Sct, St, np);
+            }
             if (rest > 0) {
                 GP_HIP(ctx, hipEventRecord(ev_rows, s));
                 GP_HIP(ctx, hipStreamWaitEvent(s2, ev_rows, 0));

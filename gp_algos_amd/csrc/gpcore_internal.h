@@ -144,6 +144,10 @@ int gpk_init_gemm_kernels();
 // tiles of L: tile b (rows 16b..16b+15) at dinv + 256*b, element (c,k) at c + 16k; a 128-block owns 8 tiles.
 void gpk_potrf_diag128(hipStream_t s, double *A, int lda, double *dinv_k, int *d_info, int base, gp_batch bt = gp_batch());   // strides: A, dinv; d_info + 1 per problem
 // optional fused row reductions: sumsq[p] += sum_c X(p,c)^2 ; dots[p] += sum_c X(p,c) tvec[c]
+// EP: the 128 rows of the delayed columns that belong to the next site block (X <- X Lmat^-T in place, X2 = X diag(cs2), dots += X tvec)
+// and the 128 x 128 lower tile D -= X2 X^T the next block kernel reads, one workgroup (kernels_diag.hip)
+void gpk_ep_link(hipStream_t s, double *X, int ldx, const double *Lmat, const double *dinv, const double *tvec, double *dots, double *X2,
+                 const double *cs2, double *D, int ldd);
 void gpk_trsm_panel128(hipStream_t s, double *X, int M, int ldx, const double *Lkk, int ldl, const double *dinv_k, double *sumsq,
                        const double *tvec = nullptr, double *dots = nullptr, gp_batch bt = gp_batch(),   // strides: X, Lkk, dinv (no fused reductions when batched)
                        double *X2 = nullptr, const double *cs2 = nullptr);   // optional second output X2(p,c) = X(p,c) * cs2[c] (same ld as X)

@@ -261,7 +261,7 @@ __device__ __forceinline__ void trsm_load_frags(const double *__restrict__ L, in
 
 // one 16-column chunk: R = B_cb - X_prev L(cb,prev)^T on the matrix cores, then X_cb = invD_cb R with the
 // accumulator registers fed straight back as the B operand (register r carries k = fg + 4r).
-template <int CB>
+template <int CB, int XS = ::XS>
 __device__ __forceinline__ void trsm_chunk(double *xs, int sp, int fr, int fg, const double (&lf)[28],
                                            const double *__restrict__ dinv, double &ss) {
     constexpr int c0 = 16 * CB;
@@ -355,6 +355,85 @@ __global__ __launch_bounds__(256, 2) void trsm_panel128_kernel(double *__restric
         ss += __shfl_xor(ss, 16);
         ss += __shfl_xor(ss, 32);
         if (fg == 0) sumsq[row0 + sp] += ss;
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// The link between two site blocks of an EP sweep (EpParameterEstimator.scala:52-54), ONE workgroup: the 128 rows of the delayed
+// columns that belong to the next block, X <- X Lmat^-T (the row-panel solve above on a 128-row strip, eight waves x 16 rows),
+// their scaled copy X2 = X diag(c), the mean update dots += X tvec, and -- from the strip still in LDS -- the one 128 x 128 tile
+// of the rank-128 update the next block kernel reads, D(lower) -= X2 X^T.  As two launches (panel solve on 2 workgroups, tile
+// update on 36) the second re-read what the first had just written through L2/HBM, 4 us alone and 20+ us while the other
+// streams' GEMMs load the memory system; fused, the chain between two block kernels is one launch shorter as well.
+constexpr int LKS = 144;   // LDS column stride of the 128-row strip: 1152 B = 128 (mod 256)
+__global__ __launch_bounds__(512) void ep_link_kernel(double *__restrict__ X, int ldx, const double *__restrict__ L, const double *__restrict__ dinv,
+                                                      const double *__restrict__ tvec, double *__restrict__ dots, double *__restrict__ X2,
+                                                      const double *__restrict__ cs2, double *__restrict__ D, int ldd) {
+    extern __shared__ __attribute__((aligned(16))) double xs[];   // NB x LKS
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int li = (tid & 63) * 2, lc = tid >> 6;   // row pair, column (+8 per step)
+#pragma unroll
+    for (int q0 = 0; q0 < 16; q0 += 8) {
+        double2_t v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = *reinterpret_cast<const double2_t *>(X + li + (size_t)(lc + 8 * (q0 + q)) * ldx);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) *reinterpret_cast<double2_t *>(xs + (lc + 8 * (q0 + q)) * LKS + li) = v[q];
+    }
+    double fa[28], fb[28];
+    trsm_load_frags<1>(L, NB, fr, fg, fa);
+    __syncthreads();
+    const int sp = wave * 16 + fr;   // this lane's row inside the strip
+    double ss = 0.0;
+    trsm_load_frags<2>(L, NB, fr, fg, fb);
+    trsm_chunk<0, LKS>(xs, sp, fr, fg, fa, dinv, ss);
+    trsm_chunk<1, LKS>(xs, sp, fr, fg, fa, dinv, ss);
+    trsm_load_frags<3>(L, NB, fr, fg, fa);
+    trsm_chunk<2, LKS>(xs, sp, fr, fg, fb, dinv, ss);
+    trsm_load_frags<4>(L, NB, fr, fg, fb);
+    trsm_chunk<3, LKS>(xs, sp, fr, fg, fa, dinv, ss);
+    trsm_load_frags<5>(L, NB, fr, fg, fa);
+    trsm_chunk<4, LKS>(xs, sp, fr, fg, fb, dinv, ss);
+    trsm_load_frags<6>(L, NB, fr, fg, fb);
+    trsm_chunk<5, LKS>(xs, sp, fr, fg, fa, dinv, ss);
+    trsm_load_frags<7>(L, NB, fr, fg, fa);
+    trsm_chunk<6, LKS>(xs, sp, fr, fg, fb, dinv, ss);
+    trsm_chunk<7, LKS>(xs, sp, fr, fg, fa, dinv, ss);
+    (void)ss;
+    __syncthreads();
+    // the tile update first (the next block kernel waits for it), 36 lower 16 x 16 tiles over the eight waves, K = 128
+    for (int q = wave; q < 36; q += 8) {
+        int I, J;
+        tri_coords(q, I, J);
+        double4_t acc;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) acc[rr] = D[(16 * I + fr) + (size_t)(16 * J + fg + 4 * rr) * ldd];
+#pragma unroll 8
+        for (int ks = 0; ks < 32; ++ks) {
+            const int k = 4 * ks + fg;
+            const double aop = -(cs2[k] * xs[k * LKS + 16 * J + fr]);
+            const double bop = xs[k * LKS + 16 * I + fr];
+            acc = MFMA(aop, bop, acc);
+        }
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+            if (16 * I + fr >= 16 * J + fg + 4 * rr) D[(16 * I + fr) + (size_t)(16 * J + fg + 4 * rr) * ldd] = acc[rr];
+    }
+    // the solved rows, their scaled copy and the mean update
+#pragma unroll 4
+    for (int q = 0; q < 16; ++q) {
+        double2_t v = *reinterpret_cast<const double2_t *>(xs + (lc + 8 * q) * LKS + li);
+        *reinterpret_cast<double2_t *>(X + li + (size_t)(lc + 8 * q) * ldx) = v;
+        const double sc = cs2[lc + 8 * q];
+        v.x *= sc, v.y *= sc;
+        *reinterpret_cast<double2_t *>(X2 + li + (size_t)(lc + 8 * q) * ldx) = v;
+    }
+    if (tid < NB) {
+        double acc = 0.0;
+#pragma unroll 8
+        for (int c = 0; c < NB; ++c) acc = fma(xs[c * LKS + tid], tvec[c], acc);
+        dots[tid] += acc;
     }
 }
 
@@ -467,11 +546,13 @@ __global__ __launch_bounds__(64) void tile_inverse_kernel(const double *__restri
 static constexpr int POTRF_LDS = (NB * PLS + 256 + 8) * (int)sizeof(double);
 static constexpr int TRSM_LDS = NB * XS * (int)sizeof(double);
 static constexpr int STEP_LDS = (NB * LS1 + 8 * 256 + NB + 16) * (int)sizeof(double);
+static constexpr int LINK_LDS = NB * LKS * (int)sizeof(double);
 
 int gpk_init_diag_kernels() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(potrf_diag128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, POTRF_LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(trsm_panel128_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, TRSM_LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(trsm_panel128_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, TRSM_LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(ep_link_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LINK_LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(fwd_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, STEP_LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(bwd_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, STEP_LDS);
     return e == hipSuccess ? 0 : 1;
@@ -488,6 +569,10 @@ void gpk_trsm_panel128(hipStream_t s, double *X, int M, int ldx, const double *L
         hipLaunchKernelGGL(trsm_panel128_kernel<true>, dim3(M / 64, bt.count), dim3(256), TRSM_LDS, s, X, ldx, Lkk, ldl, dinv, sumsq, tvec, dots, bt, X2, cs2);
     else
         hipLaunchKernelGGL(trsm_panel128_kernel<false>, dim3(M / 64, bt.count), dim3(256), TRSM_LDS, s, X, ldx, Lkk, ldl, dinv, sumsq, tvec, dots, bt, X2, cs2);
+}
+void gpk_ep_link(hipStream_t s, double *X, int ldx, const double *Lmat, const double *dinv, const double *tvec, double *dots, double *X2,
+                 const double *cs2, double *D, int ldd) {
+    hipLaunchKernelGGL(ep_link_kernel, dim3(1), dim3(512), LINK_LDS, s, X, ldx, Lmat, dinv, tvec, dots, X2, cs2, D, ldd);
 }
 void gpk_fwd_step(hipStream_t s, const double *L, int ldl, const double *dinv_k, double *t, double *sol, int k0, int r) {
     int grid = r > 0 ? (r + 255) / 256 : 1;
