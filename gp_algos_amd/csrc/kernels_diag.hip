@@ -373,16 +373,24 @@ __global__ __launch_bounds__(512) void ep_link_kernel(double *__restrict__ X, in
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
     const int li = (tid & 63) * 2, lc = tid >> 6;   // row pair, column (+8 per step)
+    {   // strip by LDS-DMA: one wave instruction = one 128-row column (1 KiB), 16 per wave, all in flight, no staging registers
+        const double *src = X + lane * 2 + (size_t)wave * ldx;
 #pragma unroll
-    for (int q0 = 0; q0 < 16; q0 += 8) {
-        double2_t v[8];
+        for (int q = 0; q < NB / 8; ++q) __builtin_amdgcn_global_load_lds(src + (size_t)(8 * q) * ldx, xs + (wave + 8 * q) * LKS, 16, 0, 0);
+    }
+    // this wave's tiles of D (q = wave, wave + 8, ...; at most 5): fetched now, under the solve -- they do not depend on it
+    double4_t dacc[5];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = *reinterpret_cast<const double2_t *>(X + li + (size_t)(lc + 8 * (q0 + q)) * ldx);
+    for (int u = 0; u < 5; ++u) {
+        const int q = wave + 8 * u;
+        int I = 0, J = 0;
+        if (q < 36) tri_coords(q, I, J);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) *reinterpret_cast<double2_t *>(xs + (lc + 8 * (q0 + q)) * LKS + li) = v[q];
+        for (int rr = 0; rr < 4; ++rr) dacc[u][rr] = (q < 36) ? D[(16 * I + fr) + (size_t)(16 * J + fg + 4 * rr) * ldd] : 0.0;
     }
     double fa[28], fb[28];
     trsm_load_frags<1>(L, NB, fr, fg, fa);
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the DMA has landed (and the loads above)
     __syncthreads();
     const int sp = wave * 16 + fr;   // this lane's row inside the strip
     double ss = 0.0;
@@ -403,12 +411,13 @@ __global__ __launch_bounds__(512) void ep_link_kernel(double *__restrict__ X, in
     (void)ss;
     __syncthreads();
     // the tile update first (the next block kernel waits for it), 36 lower 16 x 16 tiles over the eight waves, K = 128
-    for (int q = wave; q < 36; q += 8) {
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+        const int q = wave + 8 * u;
+        if (q >= 36) break;
         int I, J;
         tri_coords(q, I, J);
-        double4_t acc;
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) acc[rr] = D[(16 * I + fr) + (size_t)(16 * J + fg + 4 * rr) * ldd];
+        double4_t acc = dacc[u];
 #pragma unroll 8
         for (int ks = 0; ks < 32; ++ks) {
             const int k = 4 * ks + fg;
