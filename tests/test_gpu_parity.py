@@ -153,6 +153,25 @@ def test_potrf_not_positive_definite(ctx):
     assert e.value.info == 2
 
 
+@pytest.mark.parametrize("k,bad", [(0, -1.0), (15, 0.0), (16, -2.0), (17, float("nan")), (127, -1.0), (128, 0.0), (129, -1e-300), (299, -1.0)])
+def test_potrf_reports_the_first_bad_pivot(ctx, k, bad):
+    """dpotrf's info = 1-based index of the first non-positive pivot (breeze.linalg.cholesky throws there): at tile, micro-panel and block
+    boundaries, for negative, zero and NaN pivots, with a second bad pivot further on that must not be the one reported."""
+    from gp_algos_amd._lib import NotPositiveDefinite
+    n = 300
+    rng = np.random.default_rng(k)
+    Q = 0.05 * rng.standard_normal((n, n))
+    A = np.eye(n) * 2.0 + Q @ Q.T
+    A[k, :] = 0.0
+    A[:, k] = 0.0
+    A[k, k] = bad                       # the Schur complement at k is exactly `bad`: row/column k are otherwise zero
+    if k + 40 < n:
+        A[k + 40, k + 40] = -5.0
+    with pytest.raises(NotPositiveDefinite) as e:
+        ctx.potrf_lower(A)
+    assert e.value.info == k + 1
+
+
 def test_trsm_reference_kats(ctx):  # MatrixUtilsTest.scala:24-63
     Lm = np.array([[0.3, 0.0, 0.0], [0.2, 0.3, 0.0], [0.1, 0.99, 0.11]])
     U = np.array([[0.4, 0.1, 0.9], [0.0, 0.2, 0.89], [0.0, 0.0, 0.5]])
