@@ -355,6 +355,195 @@ __global__ __launch_bounds__(64 * EP_BLOCK_WAVES) void ep_block_kernel(int n, in
     }
 }
 
+// ---- the same block of sites with the site loop on ONE wave and no barrier per site (GPCORE_EP_BLOCK=1, default) ----
+// In ep_block_kernel a site iteration is ~1950 cycles of which the chain of dependent fp64 operations is ~1100: the rest is the
+// barrier and the LDS hand-overs between the scalar lane and the row threads on either side of it.  Here one wave owns all 128
+// rows (lane l: rows l and l + 64) and the values a site needs from "its" row are lane broadcasts (v_readlane), so a site costs
+// its chain plus a handful of instructions; everything that does not depend on the site's result -- the part of the next column
+// that comes from the chunk's earlier sites -- is independent code in the same instruction stream and fills the issue slots the
+// chain leaves empty.  The chunk's 16 finished columns and their c live in registers (statically indexed: the 16 sites of a chunk
+// are unrolled), columns also go to LDS for the matrix-core tiles and the unit-lower factor.  Barriers only at chunk boundaries:
+// the next chunk's own tile column is updated at once (one tile per wave), the tile columns to the right of it by waves 1-7 while
+// wave 0 runs the next chunk.  Outputs (:45-51) are computed for all sites together after the last one.
+struct ep_site_regs {
+    double S0[16], S1[16];     // this chunk's finished columns, rows lane and lane + 64
+    double cq[16];             // c of this chunk's sites
+    double m0, m1;             // running mean of rows lane, lane + 64
+    double p0, p1;             // column of the site about to be processed, without the term of the site before it
+    double sp0, sp1;           // previous site's finished column (rows lane, lane + 64)
+    double c_prev, coef_prev;
+};
+
+template <int P, bool HI, bool FULL>
+__device__ __forceinline__ void ep_site_steps(ep_site_regs &st, double *A, double *cs, double *cf, double *ob, const double *tb,
+                                              const double *nb, const double *yb, int cs0, int bsz, int lane) {
+    constexpr int LS = GP_NB + 1;
+    if constexpr (P < 16) {
+        const int t = cs0 + P;
+        if (FULL || t < bsz) {     // FULL: all 16 sites of the chunk exist -- no branches, one basic block per chunk
+            const int own = t & 63;
+            // column t becomes final (the term of site t-1 was the only one missing), the mean takes site t-1's update
+            double s0 = st.p0, s1 = st.p1;
+            if constexpr (P > 0) {
+                const double w = st.c_prev * rl64(HI ? st.S1[P - 1] : st.S0[P - 1], own);     // c_{t-1} S[t, t-1]
+                s0 = fma(-w, st.S0[P - 1], s0);
+                s1 = fma(-w, st.S1[P - 1], s1);
+            }
+            st.m0 = fma(st.sp0, st.coef_prev, st.m0);      // (site 0 of the block: sp = coef_prev = 0)
+            st.m1 = fma(st.sp1, st.coef_prev, st.m1);
+            st.S0[P] = s0, st.S1[P] = s1, st.sp0 = s0, st.sp1 = s1;
+            A[lane + t * LS] = s0;
+            A[lane + 64 + t * LS] = s1;
+            const double sii = rl64(HI ? s1 : s0, own);
+            const double mui = rl64(HI ? st.m1 : st.m0, own);
+            const double to = tb[t], no = nb[t], yi = yb[t];
+            // column t+1 without the term of site t: independent of the chain below
+            if constexpr (P < 15) {
+                if (FULL || t + 1 < bsz) {
+                    const int own1 = (t + 1) & 63;
+                    double q0 = A[lane + (t + 1) * LS], q1 = A[lane + 64 + (t + 1) * LS];
+#pragma unroll
+                    for (int q = 0; q < P; ++q) {
+                        const double wq = st.cq[q] * rl64(HI ? st.S1[q] : st.S0[q], own1);
+                        q0 = fma(-wq, st.S0[q], q0);
+                        q1 = fma(-wq, st.S1[q], q1);
+                    }
+                    st.p0 = q0, st.p1 = q1;
+                }
+            }
+            // the site chain (tilted moments only; see ep_block_kernel)
+            const double rs = rcp_nr(sii);
+            const double cvr = sii * rcp_nr(fma(-to, sii, 1.0));
+            const double nc = fma(mui, rs, -no);
+            const double cm = nc * cvr;
+            const double rt = rsqrt(1.0 + cvr);
+            const double z = (yi * cm) * rt;
+            const double Phi = 0.5 * (1.0 + erf(z * 0.70710678118654752440));
+            const double ratio = dnorm_d(z) * rcp_nr(Phi);
+            const double mi_hat = cm + (yi * cvr) * (ratio * rt);
+            const double sg_hat = cvr - (cvr * cvr) * (ratio * (z + ratio)) * (rt * rt);
+            const double c = (sii - sg_hat) * (rs * rs);
+            const double coef = (mi_hat - mui) * rs;
+            st.cq[P] = c, st.c_prev = c, st.coef_prev = coef;
+            // (every lane holds the same values and writes them to the same addresses: no branch for one lane's sake)
+            cs[t] = c;
+            cf[t] = coef;
+            double *o = ob + 5 * t;
+            o[0] = rs, o[1] = to, o[2] = sg_hat, o[3] = mi_hat, o[4] = nc;
+        }
+        ep_site_steps<P + 1, HI, FULL>(st, A, cs, cf, ob, tb, nb, yb, cs0, bsz, lane);
+    }
+}
+
+constexpr int EP_BLOCK1_LDS = (GP_NB * (GP_NB + 1) + 8 * GP_NB + 5 * GP_NB + 16) * (int)sizeof(double);
+constexpr int EP_BLOCK1_WAVES = 4;   // wave 0: the site loop (it needs > 256 registers: four waves leave it 512); waves 1-3: tiles
+__global__ __launch_bounds__(64 * EP_BLOCK1_WAVES) void ep_block1_kernel(int n, int np, int i0, int bsz, const double *__restrict__ Sig0,
+                                                                        const double *__restrict__ mu, const int *__restrict__ y,
+                                                                        double *__restrict__ tau, double *__restrict__ nu,
+                                                                        double *__restrict__ cav_tau, double *__restrict__ cav_nu,
+                                                                        double *__restrict__ cvec, double *__restrict__ ncoef,
+                                                                        double *__restrict__ Lmat, double *__restrict__ Ldinv) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    constexpr int LS = GP_NB + 1;
+    double *A = sm;                   // column c: Sigma0[blk, i0+c] until site c is processed, afterwards s_c[blk]
+    double *cs = sm + GP_NB * LS;     // c
+    double *cf = cs + GP_NB;          // coef
+    double *mb = cf + GP_NB;          // mu restricted to the block (staging only)
+    double *tb = mb + GP_NB;          // site parameters and labels, staged once; tb / nb receive the new ones at the end
+    double *nb = tb + GP_NB;
+    double *yb = nb + GP_NB;
+    double *ctb = yb + GP_NB;
+    double *cnb = ctb + GP_NB;
+    double *ob = cnb + GP_NB;         // [site][5]: 1/sii, tau_old, sg, mi, cavity nu
+    const int tid = threadIdx.x, r = tid, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
+    const bool rowthread = tid < GP_NB;
+    {   // the block of Sigma0: every thread half of a row's columns, 16 loads in flight
+        const int rr = tid & (GP_NB - 1), cq0 = 64 * (tid >> 7);
+#pragma unroll
+        for (int c0 = 0; c0 < 64; c0 += 16) {
+            double v[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) v[c] = Sig0[(i0 + rr) + (size_t)(i0 + cq0 + c0 + c) * np];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) A[rr + (cq0 + c0 + c) * LS] = v[c];
+        }
+    }
+    if (rowthread) {
+        mb[r] = (i0 + r < n) ? mu[i0 + r] : 0.0;
+        cs[r] = 0.0;
+        cf[r] = 0.0;
+        const bool live = r < bsz;
+        tb[r] = live ? tau[i0 + r] : 0.0;
+        nb[r] = live ? nu[i0 + r] : 0.0;
+        yb[r] = live ? (double)y[i0 + r] : 0.0;
+    }
+    __syncthreads();
+    const int jtiles = (bsz + 15) >> 4;
+    ep_site_regs st;
+    if (wave == 0) {
+        st.m0 = mb[lane], st.m1 = mb[lane + 64];
+        st.sp0 = st.sp1 = 0.0, st.c_prev = st.coef_prev = 0.0;
+    }
+    for (int ch = 0; ch < jtiles; ++ch) {
+        const int cs0 = 16 * ch;
+        if (wave == 0) {
+            st.p0 = A[lane + cs0 * LS];          // the chunk's first column is final as it stands (the boundary tiles applied every earlier site)
+            st.p1 = A[lane + 64 + cs0 * LS];
+            const bool full = cs0 + 16 <= bsz;
+            if (cs0 < 64) {
+                if (full) ep_site_steps<0, false, true>(st, A, cs, cf, ob, tb, nb, yb, cs0, bsz, lane);
+                else ep_site_steps<0, false, false>(st, A, cs, cf, ob, tb, nb, yb, cs0, bsz, lane);
+            } else {
+                if (full) ep_site_steps<0, true, true>(st, A, cs, cf, ob, tb, nb, yb, cs0, bsz, lane);
+                else ep_site_steps<0, true, false>(st, A, cs, cf, ob, tb, nb, yb, cs0, bsz, lane);
+            }
+        } else if (ch > 0) {
+            // the chunk closed at the last boundary, applied to the tile columns right of the current chunk's: J = ch+1 .. jtiles-1, I = J .. 7
+            int k = wave - 1;
+            for (int J = ch + 1; J < jtiles; ++J)
+                for (int I = J; I < 8; ++I, k = (k == 0 ? EP_BLOCK1_WAVES - 2 : k - 1))
+                    if (k == 0) ep_chunk_tile(A, cs, LS, I, J, cs0 - 16, fr, fg);
+        }
+        __syncthreads();
+        if (ch + 1 < jtiles) {
+            // the finished chunk applied to the next chunk's own tile column
+            const int jc = ch + 1;
+            for (int I = jc + wave; I < 8; I += EP_BLOCK1_WAVES) ep_chunk_tile(A, cs, LS, I, jc, cs0, fr, fg);
+            __syncthreads();
+        }
+    }
+    // outputs of all sites (:45-51 as written), one thread per site
+    if (rowthread && r < bsz) {
+        const double *o = ob + 5 * r;
+        const double tc = o[0] - o[1];                              // cavity tau  :45
+        const double isg = rcp_nr(o[2]);
+        const double dtau = isg - tc - o[1];                        // :49
+        tau[i0 + r] = o[1] + dtau;                                  // :50
+        nu[i0 + r] = o[3] * isg - o[4];                             // :51
+        cav_tau[i0 + r] = tc;
+        cav_nu[i0 + r] = o[4];
+        cvec[r] = cs[r];
+        ncoef[r] = cf[r];
+    }
+    if (rowthread) {
+        if (r >= bsz) { cvec[r] = 0.0; ncoef[r] = 0.0; }
+        for (int c = 0; c < GP_NB; ++c)
+            Lmat[r + (size_t)c * GP_NB] = (r == c) ? 1.0 : ((r > c && c < bsz) ? A[r + c * LS] * cs[c] : 0.0);
+    }
+    if (wave == 2 || wave == 3) {   // unit-lower tile inverses of Lmat, as in ep_block_kernel
+        const int c0 = 16 * (4 * (wave - 2) + fg);
+        double row[16], sv[16], x[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            row[k] = (c0 + k < bsz) ? A[(c0 + fr) + (c0 + k) * LS] * cs[c0 + k] : 0.0;
+            sv[k] = (k == fr) ? 1.0 : 0.0;
+        }
+        tile_unit_inverse<0>(row, sv, x);
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) Ldinv[(c0 / 16) * 256 + rr + 16 * fr] = x[rr];
+    }
+}
+
 // D (128 x 128, lower triangle, leading dimension ldd) -= Sc St^T with Sc, St the 128 x 128 row blocks (leading dimension ld)
 // of the scaled and unscaled delayed columns: the ONE tile of a block's rank-128 update that the next block kernel reads.
 // It sits on the serial chain of the sweep, where the general 128 x 128-tile GEMM would run it on a single CU (14 us of
@@ -625,6 +814,7 @@ gp_status ep_alloc(gp_ctx *ctx, int n, const int32_t *y, gp_ep **out) {
     for (int i = 0; i < n; ++i) GP_REQUIRE(ctx, y[i] == 1 || y[i] == -1, "targets must contain values from set {-1,1}");
     GP_HIP(ctx, hipSetDevice(ctx->device));
     GP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(ep_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, EP_BLOCK_LDS));
+    GP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(ep_block1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, EP_BLOCK1_LDS));
     gp_ep *ep = new (std::nothrow) gp_ep();
     if (!ep) return GP_ENOMEM;
     ep->ctx = ctx; ep->n = n; ep->np = gp_pad(n); ep->ldl = 2 * ep->np;
@@ -709,6 +899,7 @@ gp_status gp_ep_sweep(gp_ep *ep, int nsweeps, double *tau, double *nu, int *info
     // launches are faster (the single workgroup is bound by one CU's matrix pipe: n = 4096 end-of-sweep form 106.9 vs 103.3 sweeps/s),
     // under the streamed refactorisation's GEMMs the fused one is (167.4 vs 163.9) -- so it follows `pipe` (GPCORE_EP_LINK overrides)
     const bool fused_link = [pipe] { const char *e = getenv("GPCORE_EP_LINK"); return e ? atoi(e) != 0 : pipe; }();
+    const bool block1 = [] { const char *e = getenv("GPCORE_EP_BLOCK"); return !e || atoi(e) != 0; }();   // site loop on one wave (0: one barrier per site)
     const bool far_split = [] { const char *e = getenv("GPCORE_EP_FAR"); return !e || atoi(e) != 0; }();
     const bool sig_small = [] { const char *e = getenv("GPCORE_EP_SIG_K128"); return e && atoi(e) != 0; }();
     const int nblk = np / GP_NB;
@@ -758,8 +949,12 @@ gp_status gp_ep_sweep(gp_ep *ep, int nsweeps, double *tau, double *nu, int *info
             const int par = b & 1;
             double *Lmat = ep->blk + (size_t)par * (GP_NB * GP_NB + 8 * 256), *bdinv = Lmat + GP_NB * GP_NB;
             double *cvec = ep->cvec + (size_t)par * 2 * GP_NB, *ncoef = cvec + GP_NB;   // c and coef of every site of the block
-            hipLaunchKernelGGL(ep_block_kernel, dim3(1), dim3(64 * EP_BLOCK_WAVES), EP_BLOCK_LDS, s, n, np, i0, bsz, ep->Sig, ep->mu(), ep->y,
-                               ep->tau(), ep->nu(), ep->cav_tau(), ep->cav_nu(), cvec, ncoef, Lmat, bdinv);
+            if (block1)
+                hipLaunchKernelGGL(ep_block1_kernel, dim3(1), dim3(64 * EP_BLOCK1_WAVES), EP_BLOCK1_LDS, s, n, np, i0, bsz, ep->Sig, ep->mu(), ep->y,
+                                   ep->tau(), ep->nu(), ep->cav_tau(), ep->cav_nu(), cvec, ncoef, Lmat, bdinv);
+            else
+                hipLaunchKernelGGL(ep_block_kernel, dim3(1), dim3(64 * EP_BLOCK_WAVES), EP_BLOCK_LDS, s, n, np, i0, bsz, ep->Sig, ep->mu(), ep->y,
+                                   ep->tau(), ep->nu(), ep->cav_tau(), ep->cav_nu(), cvec, ncoef, Lmat, bdinv);
             hipEvent_t ev_fac = ep->ev[4 * b], ev_rows = ep->ev[4 * b + 1], ev_side = ep->ev[4 * b + 2], ev_vt = ep->ev[4 * b + 3];
             if (overlap) GP_HIP(ctx, hipEventRecord(ev_fac, s));
             if (pipe) {
