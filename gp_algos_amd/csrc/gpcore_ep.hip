@@ -372,6 +372,8 @@ struct ep_site_regs {
     double p0, p1;             // column of the site about to be processed, without the term of the site before it
     double sp0, sp1;           // previous site's finished column (rows lane, lane + 64)
     double c_prev, coef_prev;
+    double a0, a1;             // column t+1 of A for rows lane, lane + 64, fetched from LDS one site ahead
+    double to_n, no_n, yi_n;   // site parameters of the site about to be processed, fetched one site ahead
 };
 
 template <int P, bool HI, bool FULL>
@@ -396,12 +398,16 @@ __device__ __forceinline__ void ep_site_steps(ep_site_regs &st, double *A, doubl
             A[lane + 64 + t * LS] = s1;
             const double sii = rl64(HI ? s1 : s0, own);
             const double mui = rl64(HI ? st.m1 : st.m0, own);
-            const double to = tb[t], no = nb[t], yi = yb[t];
+            const double to = st.to_n, no = st.no_n, yi = st.yi_n;
             // column t+1 without the term of site t: independent of the chain below
             if constexpr (P < 15) {
                 if (FULL || t + 1 < bsz) {
                     const int own1 = (t + 1) & 63;
-                    double q0 = A[lane + (t + 1) * LS], q1 = A[lane + 64 + (t + 1) * LS];
+                    double q0 = st.a0, q1 = st.a1;
+                    // (LDS reads one site ahead of their use: column t+2, parameters of site t+1; clamped inside the arrays)
+                    const int t2 = (P < 14 && t + 2 < GP_NB) ? t + 2 : t + 1;
+                    st.a0 = A[lane + t2 * LS], st.a1 = A[lane + 64 + t2 * LS];
+                    st.to_n = tb[t + 1], st.no_n = nb[t + 1], st.yi_n = yb[t + 1];
 #pragma unroll
                     for (int q = 0; q < P; ++q) {
                         const double wq = st.cq[q] * rl64(HI ? st.S1[q] : st.S0[q], own1);
@@ -489,6 +495,9 @@ __global__ __launch_bounds__(64 * EP_BLOCK1_WAVES) void ep_block1_kernel(int n, 
         if (wave == 0) {
             st.p0 = A[lane + cs0 * LS];          // the chunk's first column is final as it stands (the boundary tiles applied every earlier site)
             st.p1 = A[lane + 64 + cs0 * LS];
+            const int c1 = cs0 + 1 < GP_NB ? cs0 + 1 : cs0;
+            st.a0 = A[lane + c1 * LS], st.a1 = A[lane + 64 + c1 * LS];
+            st.to_n = tb[cs0], st.no_n = nb[cs0], st.yi_n = yb[cs0];
             const bool full = cs0 + 16 <= bsz;
             if (cs0 < 64) {
                 if (full) ep_site_steps<0, false, true>(st, A, cs, cf, ob, tb, nb, yb, cs0, bsz, lane);
@@ -603,25 +612,28 @@ __global__ void ep_winit_kernel(double *__restrict__ W, int ldw, const double *_
     }
 }
 // Site block k0's precisions are final: column k of the block (rows k .. 2 np - 1 of the trailing matrix and of the rows that
-// ride along) takes its factor s_k, rows inside the block take s_i as well, the diagonal gains the identity of B; st <- s.
-__global__ void ep_wscale_cols_kernel(double *__restrict__ W, int ldw, int np, int k0, const double *__restrict__ tau, int n,
-                                      double *__restrict__ st) {
-    const int k = k0 + blockIdx.y;
-    const double sk = (k < n) ? sqrt(tau[k]) : 0.0;
-    if (blockIdx.x == 0 && threadIdx.x == 0) st[k] = sk;
-    double *wk = W + (size_t)k * ldw;
-    for (int i = k + blockIdx.x * blockDim.x + threadIdx.x; i < 2 * np; i += gridDim.x * blockDim.x) {
-        double f = sk;
-        if (i < k0 + GP_NB) f *= (i < n) ? sqrt(tau[i]) : 0.0;
-        const double v = wk[i] * f;
-        wk[i] = (i == k) ? 1.0 + v : v;
+// ride along) takes its factor s_k, rows inside the block take s_i as well, the diagonal gains the identity of B; st <- s
+// (blockIdx.y < 128: one column each).  The block's rows of the factor computed so far (columns < k0) take s_i (blockIdx.y >= 128:
+// two columns per workgroup).  One launch for both parts.
+__global__ __launch_bounds__(256) void ep_wscale_kernel(double *__restrict__ W, int ldw, int np, int k0, const double *__restrict__ tau, int n,
+                                                        double *__restrict__ st) {
+    if (blockIdx.y < GP_NB) {
+        const int k = k0 + blockIdx.y;
+        const double sk = (k < n) ? sqrt(tau[k]) : 0.0;
+        if (blockIdx.x == 0 && threadIdx.x == 0) st[k] = sk;
+        double *wk = W + (size_t)k * ldw;
+        for (int i = k + blockIdx.x * blockDim.x + threadIdx.x; i < 2 * np; i += gridDim.x * blockDim.x) {
+            double f = sk;
+            if (i < k0 + GP_NB) f *= (i < n) ? sqrt(tau[i]) : 0.0;
+            const double v = wk[i] * f;
+            wk[i] = (i == k) ? 1.0 + v : v;
+        }
+    } else {
+        const int i = k0 + (threadIdx.x & (GP_NB - 1));
+        const double si = (i < n) ? sqrt(tau[i]) : 0.0;
+        const int wg = (blockIdx.y - GP_NB) * gridDim.x + blockIdx.x, nwg = (gridDim.y - GP_NB) * gridDim.x;
+        for (int j = wg * 2 + (threadIdx.x >> 7); j < k0; j += nwg * 2) W[i + (size_t)j * ldw] *= si;
     }
-}
-// ... and the block's rows of the factor computed so far (columns < k0) take s_i
-__global__ void ep_wscale_rows_kernel(double *__restrict__ W, int ldw, int k0, const double *__restrict__ tau, int n) {
-    const int i = k0 + (threadIdx.x & (GP_NB - 1));
-    const double si = (i < n) ? sqrt(tau[i]) : 0.0;
-    for (int j = blockIdx.x * 2 + (threadIdx.x >> 7); j < k0; j += gridDim.x * 2) W[i + (size_t)j * ldw] *= si;
 }
 
 __global__ void mirror_lower_kernel(double *__restrict__ A, int np) {
@@ -959,9 +971,11 @@ gp_status gp_ep_sweep(gp_ep *ep, int nsweeps, double *tau, double *nu, int *info
             if (overlap) GP_HIP(ctx, hipEventRecord(ev_fac, s));
             if (pipe) {
                 GP_HIP(ctx, hipStreamWaitEvent(s3, ev_fac, 0));
-                hipLaunchKernelGGL(ep_wscale_cols_kernel, dim3((2 * np - i0 + 1023) / 1024, GP_NB), dim3(256), 0, s3, ep->L, ep->ldl, np, i0,
-                                   ep->tau(), n, ep->st());
-                if (i0 > 0) hipLaunchKernelGGL(ep_wscale_rows_kernel, dim3(std::min(i0 / 2, 1024)), dim3(256), 0, s3, ep->L, ep->ldl, i0, ep->tau(), n);
+                {
+                    const int gx = (2 * np - i0 + 1023) / 1024;
+                    hipLaunchKernelGGL(ep_wscale_kernel, dim3(gx, GP_NB + std::min((i0 / 2 + gx - 1) / gx, 256)), dim3(256), 0, s3, ep->L, ep->ldl, np, i0,
+                                       ep->tau(), n, ep->st());
+                }
                 gpi_chol_panel_step(ctx, s3, ep->L, np, ep->ldl, ep->dinv, np, i0, ev_vt, far_split ? s4 : nullptr, ep->ev_parta);
                 // the finished columns of Vt go into the next covariance on a stream of their own, an outer panel (K = 512) at a time;
                 // the last outer panel in two pieces so that only a K = 128 update is left after the last block kernel

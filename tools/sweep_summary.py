@@ -12,17 +12,17 @@ cols = [r[1] for r in cur.execute(f"pragma table_info({kd})")]
 qcol = "queue_id" if "queue_id" in cols else "stream_id"
 rows = cur.execute(f"select s.kernel_name, d.start, d.end, d.{qcol} from {kd} d join {ks} s on d.kernel_id=s.id order by d.start").fetchall()
 starts = [i for i, r in enumerate(rows) if "ep_winit" in r[0]]
-blocks = [i for i, r in enumerate(rows) if "ep_block_kernel" in r[0]]
+blocks = [i for i, r in enumerate(rows) if "ep_block" in r[0]]
 if len(starts) < 2:
     sys.exit("no streamed sweeps in this trace")
 first_block = max(b for b in blocks if b < starts[-1])     # block kernel 0 of the last sweep starts just before its winit
 sel = rows[first_block:]
 t0 = sel[0][1]
 end = max(r[2] for r in sel)
-bk = [(r[1] - t0) / 1e3 for r in sel if "ep_block_kernel" in r[0]]
+bk = [(r[1] - t0) / 1e3 for r in sel if "ep_block" in r[0]]
 print("sweep span %.1f us, %d block kernels, mean period %.1f us, last block kernel ends %.1f us, tail %.1f us" % (
-    (end - t0) / 1e3, len(bk), (bk[-1] - bk[0]) / max(1, len(bk) - 1), max((r[2] - t0) / 1e3 for r in sel if "ep_block_kernel" in r[0]),
-    (end - max(r[2] for r in sel if "ep_block_kernel" in r[0])) / 1e3))
+    (end - t0) / 1e3, len(bk), (bk[-1] - bk[0]) / max(1, len(bk) - 1), max((r[2] - t0) / 1e3 for r in sel if "ep_block" in r[0]),
+    (end - max(r[2] for r in sel if "ep_block" in r[0])) / 1e3))
 print("block periods:", " ".join("%.0f" % (b - a) for a, b in zip(bk, bk[1:])))
 busy = {}
 for name, st, en, q in sel:
