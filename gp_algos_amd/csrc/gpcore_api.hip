@@ -527,7 +527,7 @@ gp_status gp_ctx_create(int device, void *stream, gp_ctx **out) {
         // Streams of the EP refactorisation that runs under the site loop, beside the site loop's own side work (gp_ep_sweep).
         // side3 carries its long GEMMs (far trailing updates, next covariance); GPCORE_RESERVED_CUS_EP (default 96 = 12 per XCD)
         // CUs are kept free of them, or the site loop's side stream -- whose work the serial chain waits for one block later --
-        // is starved whenever they run (n = 4096 sweeps/s with 32 / 64 / 96 / 128 reserved: 155.7 / 159.7 / 161.9 / 161.2).
+        // is starved whenever they run (n = 4096 sweeps/s with 32 / 64 / 96 / 128 reserved: 161.3 / 171.3 / 177.2 / 163.9).
         int reserved_ep = reserved > 0 ? 96 : 0;
         if (const char *rc = getenv("GPCORE_RESERVED_CUS_EP")) reserved_ep = atoi(rc);
         // side2 carries the factorisation chain: its workgroups are short-lived (quarter-size tiles) but its single-workgroup
