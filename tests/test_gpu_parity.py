@@ -400,6 +400,25 @@ def test_ep_streamed_refactorisation_vs_oracle_and_end_of_sweep_form(ctx, monkey
         assert np.max(np.abs(got["1"][key] - got["0"][key])) <= 1e-11 * np.max(np.abs(got["0"][key])), key
 
 
+@pytest.mark.parametrize("n,sweeps", [(130, 2), (300, 3), (700, 2)])
+def test_ep_block_kernel_forms_vs_oracle(ctx, monkeypatch, n, sweeps):
+    """The site loop of a block on one wave without barriers (default) and the earlier one-barrier-per-site kernel
+    (GPCORE_EP_BLOCK=0), and the link between two blocks as one launch or two (GPCORE_EP_LINK): all against the oracle."""
+    from gp_algos_amd import _lib as L
+    from gp_algos_amd.core import EpClassifierState
+    p, K, y = _ep_problem(n, seed=n + 3)
+    o = orc.ep_estimate(K, y, sweeps)
+    for block, link in (("1", "1"), ("1", "0"), ("0", "1"), ("0", "0")):
+        monkeypatch.setenv("GPCORE_EP_BLOCK", block)
+        monkeypatch.setenv("GPCORE_EP_LINK", link)
+        ep = EpClassifierState(ctx, K, y)
+        tau, nu = ep.sweep(sweeps)
+        got = dict(tau=tau, nu=nu, mu=ep.get(L.GP_EP_GET_MU), Sigma=ep.get(L.GP_EP_GET_SIGMA), cav_tau=ep.get(L.GP_EP_GET_CAV_TAU))
+        ep.close()
+        for key, val in got.items():
+            assert np.max(np.abs(val - o[key])) <= TOL_EP * np.max(np.abs(o[key])), (block, link, key)
+
+
 def test_ep_sweeps_one_at_a_time_equal_batched(ctx):
     from gp_algos_amd.core import EpClassifierState
     _, K, y = _ep_problem(150, seed=3)
