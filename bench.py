@@ -305,7 +305,7 @@ def run_secondary(args):
                               "algorithmic_tflops": tf, "frac_of_fp64_mfma_peak": tf / PEAK_FP64_MFMA_TFLOPS,
                               "executed_tflops": tf_exec, "executed_frac_of_fp64_mfma_peak": tf_exec / PEAK_FP64_MFMA_TFLOPS,
                               "critical_path_note": "a sweep is bound by the serial site chain (one single-workgroup kernel per 128 sites, "
-                                                    "~0.85 us per site: a chain of dependent fp64 operations), not by a throughput roofline; "
+                                                    "~0.70 us per site: a chain of dependent fp64 operations), not by a throughput roofline; "
                                                     "all matrix work runs on three side streams under it (profiles/: sweep summary)",
                               "executed_flops_note": "the sweep executes 2 2/3 n^3 (trailing-only rank-128 updates n^3/3, Cholesky n^3/3, "
                                                      "V n^3, Sigma n^3), the 4 1/3 n^3 of SURVEY 8(d) counts full-square rank-1 updates",
