@@ -1,8 +1,10 @@
-"""Where one site iteration of ep_block_kernel goes (lab): needs a library built with -DEP_STAMPS
+"""Where one site iteration of ep_block_kernel (the one-barrier-per-site form: run with GPCORE_EP_BLOCK=0) goes (lab): needs a library built with -DEP_STAMPS
    (hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DEP_STAMPS -o gp_algos_amd/libgpcore.so gp_algos_amd/csrc/*.hip)."""
 import ctypes as C
 import os
 import sys
+
+os.environ.setdefault("GPCORE_EP_BLOCK", "0")   # the stamps live in the one-barrier-per-site kernel
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np  # noqa: E402
