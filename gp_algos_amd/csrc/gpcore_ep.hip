@@ -384,10 +384,18 @@ __device__ __forceinline__ void ep_site_steps(ep_site_regs &st, double *A, doubl
         const int t = cs0 + P;
         if (FULL || t < bsz) {     // FULL: all 16 sites of the chunk exist -- no branches, one basic block per chunk
             const int own = t & 63;
-            // column t becomes final (the term of site t-1 was the only one missing), the mean takes site t-1's update
+            // What the chain needs from row t, as lane broadcasts of values that were final BEFORE site t-1's result: its column entry
+            // without site t-1's term (Pv), S[t, t-1] (Bv) and its mean without site t-1's update (Mv) -- two operations then
+            // separate (c, coef) of site t-1 from the start of this chain: s_ii = Pv - c Bv^2, mu_i = Mv + Bv coef.
+            const double Pv = rl64(HI ? st.p1 : st.p0, own);
+            const double Bv = rl64(HI ? st.sp1 : st.sp0, own);          // (first site of the block: sp = 0)
+            const double Mv = rl64(HI ? st.m1 : st.m0, own);
+            const double sii = (P > 0) ? fma(-(st.c_prev * Bv), Bv, Pv) : Pv;    // chunk start: the boundary tiles applied site t-1 already
+            const double mui = fma(Bv, st.coef_prev, Mv);
+            // column t becomes final for every row (the term of site t-1 was the only one missing), the mean takes site t-1's update
             double s0 = st.p0, s1 = st.p1;
             if constexpr (P > 0) {
-                const double w = st.c_prev * rl64(HI ? st.S1[P - 1] : st.S0[P - 1], own);     // c_{t-1} S[t, t-1]
+                const double w = st.c_prev * Bv;                        // c_{t-1} S[t, t-1]
                 s0 = fma(-w, st.S0[P - 1], s0);
                 s1 = fma(-w, st.S1[P - 1], s1);
             }
@@ -396,8 +404,6 @@ __device__ __forceinline__ void ep_site_steps(ep_site_regs &st, double *A, doubl
             st.S0[P] = s0, st.S1[P] = s1, st.sp0 = s0, st.sp1 = s1;
             A[lane + t * LS] = s0;
             A[lane + 64 + t * LS] = s1;
-            const double sii = rl64(HI ? s1 : s0, own);
-            const double mui = rl64(HI ? st.m1 : st.m0, own);
             const double to = st.to_n, no = st.no_n, yi = st.yi_n;
             // column t+1 without the term of site t: independent of the chain below
             if constexpr (P < 15) {
