@@ -919,6 +919,9 @@ gp_status gp_ep_sweep(gp_ep *ep, int nsweeps, double *tau, double *nu, int *info
     const bool fused_link = [pipe] { const char *e = getenv("GPCORE_EP_LINK"); return e ? atoi(e) != 0 : pipe; }();
     const bool block1 = [] { const char *e = getenv("GPCORE_EP_BLOCK"); return !e || atoi(e) != 0; }();   // site loop on one wave (0: one barrier per site)
     const bool far_split = [] { const char *e = getenv("GPCORE_EP_FAR"); return !e || atoi(e) != 0; }();
+    // columns of Vt per next-covariance update (GPCORE_EP_SIG_K; n = 4096 sweeps/s at 128 / 256 / 384 / 512 / 1024 / 2048: 173 / 181 / 175 / 177 /
+    // 172 / 155 -- short enough to spread the fourth stream's load evenly, long enough for the GEMM)
+    const int sig_blocks = [] { const int v = gp_env_blocks("GPCORE_EP_SIG_K"); return v >= GP_NB ? v / GP_NB : 2; }();
     const bool sig_small = [] { const char *e = getenv("GPCORE_EP_SIG_K128"); return e && atoi(e) != 0; }();
     const int nblk = np / GP_NB;
     double *partial = nullptr;
@@ -983,9 +986,9 @@ gp_status gp_ep_sweep(gp_ep *ep, int nsweeps, double *tau, double *nu, int *info
                                        ep->tau(), n, ep->st());
                 }
                 gpi_chol_panel_step(ctx, s3, ep->L, np, ep->ldl, ep->dinv, np, i0, ev_vt, far_split ? s4 : nullptr, ep->ev_parta);
-                // the finished columns of Vt go into the next covariance on a stream of their own, an outer panel (K = 512) at a time;
-                // the last outer panel in two pieces so that only a K = 128 update is left after the last block kernel
-                if ((b + 1) % (GP_OUTER / GP_NB) == 0 || b >= nblk - 2) {
+                // the finished columns of Vt go into the next covariance on a stream of their own, two blocks (K = 256) at a time;
+                // the last two blocks one by one so that only a K = 128 update is left after the last block kernel
+                if ((b + 1) % sig_blocks == 0 || b >= nblk - 2) {
                     GP_HIP(ctx, hipStreamWaitEvent(s4, ev_vt, 0));
                     const int kw = i0 + GP_NB - pend0;
                     const double *Vb = ep->L + np + (size_t)pend0 * ep->ldl;
