@@ -921,7 +921,8 @@ gp_status gp_ep_sweep(gp_ep *ep, int nsweeps, double *tau, double *nu, int *info
     const bool far_split = [] { const char *e = getenv("GPCORE_EP_FAR"); return !e || atoi(e) != 0; }();
     // columns of Vt per next-covariance update (GPCORE_EP_SIG_K; n = 4096 sweeps/s at 128 / 256 / 384 / 512 / 1024 / 2048: 173 / 181 / 175 / 177 /
     // 172 / 155 -- short enough to spread the fourth stream's load evenly, long enough for the GEMM)
-    const int sig_blocks = [] { const int v = gp_env_blocks("GPCORE_EP_SIG_K"); return v >= GP_NB ? v / GP_NB : 2; }();
+    // (n = 8192: 29.3 sweeps/s at K = 512 against 28.0 at 256, n = 2048: 423 against 406 -- 512 from np = 6144 on)
+    const int sig_blocks = [np] { const int v = gp_env_blocks("GPCORE_EP_SIG_K"); return v >= GP_NB ? v / GP_NB : (np >= 6144 ? 4 : 2); }();
     const bool sig_small = [] { const char *e = getenv("GPCORE_EP_SIG_K128"); return e && atoi(e) != 0; }();
     const int nblk = np / GP_NB;
     double *partial = nullptr;
