@@ -124,7 +124,8 @@ void chol_blocked(gp_ctx *ctx, double *A, int np, int lda, double *dinv, int ext
     // Measured with the side stream's reserved CUs spread over the XCDs (gp_ctx_create): n = 8192 fit 7.89 -> 7.40 ms, n = 4096
     // 2.79 -> 2.96 ms (the chain kernels slow down 2-4x while a full-chip GEMM runs beside them, so short factorisations lose),
     // n = 32768 198 -> 196..203 ms; the EP refactorisation (4096 rows of V riding along) 96.6 -> 99.5 sweeps/s.
-    const bool lookahead = count == 1 && (ctx->lookahead > 0 || (ctx->lookahead < 0 && rows >= 6144 && np < 16384));
+    // (re-measured with the 25 us diagonal kernel: n = 4096 1.961 -> 1.947 ms, n = 5120 2.775 -> 2.683, n = 6144 3.757 -> 3.569, n = 16384 30.85 -> 30.32, n = 24576 87.98 -> 89.39: on for 4096 rows .. np = 16384)
+    const bool lookahead = count == 1 && (ctx->lookahead > 0 || (ctx->lookahead < 0 && rows >= 4096 && np <= 16384));
     bool side_busy = false;
     // outer panel width: 512 (K = 512 trailing updates); 1024 measured 3 % faster at n = 32768 (205 -> 198.5 ms), equal at 8192
     const int outer_env = gp_env_blocks("GPCORE_OUTER");
