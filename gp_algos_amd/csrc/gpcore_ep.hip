@@ -1232,7 +1232,7 @@ gp_status gp_ep_optimize_rbf(gp_ctx *ctx, const double *X, int n, int d, int ldx
     GP_REQUIRE(ctx, X && y && theta0 && theta_out, "null pointer");
     GP_REQUIRE(ctx, n >= 1 && d >= 1 && d <= 64 && ldx >= n && max_sweeps >= 1 && max_iter >= 0 && history >= 1, "bad arguments");
     const int P = d + 2;
-    constexpr int NC = 3;   // trial steps per iteration = concurrent EP problems (GPCORE_EP_WORKERS)
+    constexpr int NC = 3;   // trial steps per iteration (evaluated by ep_eval_batched: concurrently where that pays, GPCORE_EP_WORKERS)
     auto evaluate = [&](const double *thetas, int count, double *f, double *g, int *bad) -> gp_status {
         return ep_eval_batched(ctx, X, n, d, ldx, y, thetas, count, stop_eps, max_sweeps, strict, f, g, nullptr, bad);
     };
@@ -1246,7 +1246,11 @@ static gp_status ep_eval_batched(gp_ctx *ctx, const double *X, int n, int d, int
     GP_REQUIRE(ctx, n >= 1 && d >= 1 && d <= 64 && ldx >= n && B >= 0 && max_sweeps >= 1, "bad dimensions");
     if (B == 0) return GP_OK;
     const int P = d + 2;
-    int nw = 3;
+    // Concurrent EP problems, each on its own context: with the streamed refactorisation one run keeps four streams busy and a second
+    // one only gets in its way (12 settings x 10 sweeps, aggregate sweeps/s with 1 / 2 / 3 workers: n = 2048 397 / 171 / 184, n = 4096
+    // 177 / 69 / 80); the end-of-sweep form of the small problems still gains from a second run (n = 512 1270 / 1499 / 1061, n = 1024
+    // 641 / 827 / 383).  GPCORE_EP_WORKERS overrides.
+    int nw = gp_pad(n) > 1024 ? 1 : 2;
     if (const char *e = getenv("GPCORE_EP_WORKERS")) nw = atoi(e);
     nw = std::max(1, std::min(std::min(nw, 8), B));
     std::vector<gp_ctx *> ctxs(nw, nullptr);

@@ -1,5 +1,5 @@
 """Throughput of gp_ep_lml_rbf_batched (EP LML over a grid of settings), C4-sized problem: n=4096, d=8.
-usage: python tools/ep_mesh_perf.py [B] [sweeps]   (env GPCORE_EP_WORKERS selects the concurrency)"""
+usage: python tools/ep_mesh_perf.py [B] [sweeps] [n]   (env GPCORE_EP_WORKERS selects the concurrency)"""
 import os
 import sys
 import time
@@ -11,7 +11,8 @@ from gp_algos_amd import core, synth  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 sweeps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-p = synth.config_c4()
+n = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
+p = synth.config_c4(n, 8)
 ctx = core.Context(0)
 th = p["theta"]
 thetas = np.stack([th * np.concatenate(([1.0 + 0.05 * b], np.ones(th.size - 2) * (1.0 + 0.03 * b), [1.0])) for b in range(B)])
@@ -19,5 +20,5 @@ ctx.ep_lml_rbf_batched(p["X"], p["y"], thetas[:3], stop_eps=-1.0, max_sweeps=2) 
 t0 = time.perf_counter()
 lml, sw, info = ctx.ep_lml_rbf_batched(p["X"], p["y"], thetas, stop_eps=-1.0, max_sweeps=sweeps)
 dt = time.perf_counter() - t0
-print("workers=%s B=%d sweeps=%d: %.1f ms -> %.2f settings/s, %.1f sweeps/s aggregate; lml[0]=%.6f info=%s" %
-      (os.environ.get("GPCORE_EP_WORKERS", "3"), B, sweeps, dt * 1e3, B / dt, B * sweeps / dt, lml[0], info.tolist()))
+print("n=%d workers=%s B=%d sweeps=%d: %.1f ms -> %.2f settings/s, %.1f sweeps/s aggregate; lml[0]=%.6f info=%s" %
+      (n, os.environ.get("GPCORE_EP_WORKERS", "default"), B, sweeps, dt * 1e3, B / dt, B * sweeps / dt, lml[0], info.tolist()))
