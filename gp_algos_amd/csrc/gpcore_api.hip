@@ -467,11 +467,54 @@ gp_status gpi_model_alpha(gp_model *m, double *dst) {
     return GP_OK;
 }
 // k-th helper context of `ctx` (same device, own stream and workspaces), created on first use and destroyed with it
+// The two extra streams of the EP sweep's streamed refactorisation, created on first use: every stream a context owns competes for
+// the process's few hardware queues, and contexts that never run such a sweep (the workers of the batched LML path, small EP
+// problems) are better off without them.
+gp_status gpi_ctx_ep_streams(gp_ctx *ctx) {
+    if (ctx->side2 && ctx->side3) return GP_OK;
+    GP_HIP(ctx, hipSetDevice(ctx->device));
+    hipError_t e = hipSuccess, em;
+    int reserved = 32;
+    if (const char *rc = getenv("GPCORE_RESERVED_CUS")) reserved = atoi(rc);
+    // Streams of the EP refactorisation that runs under the site loop, beside the site loop's own side work (gp_ep_sweep).
+    // side3 carries its long GEMMs (far trailing updates, next covariance); GPCORE_RESERVED_CUS_EP (default 96 = 12 per XCD)
+    // CUs are kept free of them, or the site loop's side stream -- whose work the serial chain waits for one block later --
+    // is starved whenever they run (n = 4096 sweeps/s with 32 / 64 / 96 / 128 reserved: 161.3 / 171.3 / 177.2 / 163.9).
+    int reserved_ep = reserved > 0 ? 96 : 0;
+    if (const char *rc = getenv("GPCORE_RESERVED_CUS_EP")) reserved_ep = atoi(rc);
+    // side2 carries the factorisation chain: its workgroups are short-lived (quarter-size tiles) but its single-workgroup
+    // diagonal kernel needs a whole CU's LDS, which it only finds quickly on the CUs the masked streams leave alone -- so side2
+    // itself is NOT masked.  (GPCORE_EP_CHAIN_MASK=k keeps k CUs free of side2 as well; measured with the 25 us diagonal kernel,
+    // k = 0 / 8 / 16 / 24 / 32: 163.5 / 162.7 / 163.2 / 162.3 / 164.3 sweeps/s at n = 4096 -- no effect, so the slow-down of the
+    // site loop's small kernels while the other streams' GEMMs run is not a matter of finding a free CU.)
+    const int chain_reserved = [] { const char *m = getenv("GPCORE_EP_CHAIN_MASK"); return m ? atoi(m) : 0; }();
+    for (hipStream_t *sp : {&ctx->side2, &ctx->side3}) {
+        if (e != hipSuccess) break;
+        em = hipErrorInvalidValue;
+        const int rsv = (sp == &ctx->side2) ? chain_reserved : reserved_ep;
+        if (rsv > 0 && ctx->num_cu >= 64) {
+            const int words = (ctx->num_cu + 31) / 32;
+            std::vector<uint32_t> mask(words, 0xFFFFFFFFu);
+            if (ctx->num_cu % 32) mask[words - 1] = (1u << (ctx->num_cu % 32)) - 1u;
+            for (int i = 0; i < rsv && i < ctx->num_cu; ++i) mask[i / 32] &= ~(1u << (i % 32));
+            em = hipExtStreamCreateWithCUMask(sp, (uint32_t)words, mask.data());
+        }
+        if (em != hipSuccess) { (void)hipGetLastError(); e = hipStreamCreateWithFlags(sp, hipStreamNonBlocking); }
+    }
+    if (e != hipSuccess) { GP_SET_ERR(ctx, "EP streams: %s", hipGetErrorString(e)); return GP_EHIP; }
+    return GP_OK;
+}
+
+static thread_local bool g_child_ctx = false;   // gp_ctx_create called for a helper context: no EP streams up front (gpi_ctx_ep_streams makes them if ever needed)
+
 gp_ctx *gpi_child_ctx(gp_ctx *ctx, int k) {
     ctx_ext *x = ext_of(ctx);
     while ((int)x->children.size() <= k) {
         gp_ctx *c = nullptr;
-        if (gp_ctx_create(ctx->device, nullptr, &c) != GP_OK) return nullptr;
+        g_child_ctx = true;
+        const gp_status cst = gp_ctx_create(ctx->device, nullptr, &c);
+        g_child_ctx = false;
+        if (cst != GP_OK) return nullptr;
         x->children.push_back(c);
     }
     return x->children[k];
@@ -525,32 +568,11 @@ gp_status gp_ctx_create(int device, void *stream, gp_ctx **out) {
             em = hipExtStreamCreateWithCUMask(&ctx->side, (uint32_t)words, mask.data());
         }
         if (em != hipSuccess) { (void)hipGetLastError(); e = hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking); }
-        // Streams of the EP refactorisation that runs under the site loop, beside the site loop's own side work (gp_ep_sweep).
-        // side3 carries its long GEMMs (far trailing updates, next covariance); GPCORE_RESERVED_CUS_EP (default 96 = 12 per XCD)
-        // CUs are kept free of them, or the site loop's side stream -- whose work the serial chain waits for one block later --
-        // is starved whenever they run (n = 4096 sweeps/s with 32 / 64 / 96 / 128 reserved: 161.3 / 171.3 / 177.2 / 163.9).
-        int reserved_ep = reserved > 0 ? 96 : 0;
-        if (const char *rc = getenv("GPCORE_RESERVED_CUS_EP")) reserved_ep = atoi(rc);
-        // side2 carries the factorisation chain: its workgroups are short-lived (quarter-size tiles) but its single-workgroup
-        // diagonal kernel needs a whole CU's LDS, which it only finds quickly on the CUs the masked streams leave alone -- so side2
-        // itself is NOT masked.  (GPCORE_EP_CHAIN_MASK=k keeps k CUs free of side2 as well; measured with the 25 us diagonal kernel,
-        // k = 0 / 8 / 16 / 24 / 32: 163.5 / 162.7 / 163.2 / 162.3 / 164.3 sweeps/s at n = 4096 -- no effect, so the slow-down of the
-        // site loop's small kernels while the other streams' GEMMs run is not a matter of finding a free CU.)
-        const int chain_reserved = [] { const char *m = getenv("GPCORE_EP_CHAIN_MASK"); return m ? atoi(m) : 0; }();
-        for (hipStream_t *sp : {&ctx->side2, &ctx->side3}) {
-            if (e != hipSuccess) break;
-            em = hipErrorInvalidValue;
-            const int rsv = (sp == &ctx->side2) ? chain_reserved : reserved_ep;
-            if (rsv > 0 && ctx->num_cu >= 64) {
-                const int words = (ctx->num_cu + 31) / 32;
-                std::vector<uint32_t> mask(words, 0xFFFFFFFFu);
-                if (ctx->num_cu % 32) mask[words - 1] = (1u << (ctx->num_cu % 32)) - 1u;
-                for (int i = 0; i < rsv && i < ctx->num_cu; ++i) mask[i / 32] &= ~(1u << (i % 32));
-                em = hipExtStreamCreateWithCUMask(sp, (uint32_t)words, mask.data());
-            }
-            if (em != hipSuccess) { (void)hipGetLastError(); e = hipStreamCreateWithFlags(sp, hipStreamNonBlocking); }
-        }
     }
+    // A caller's context gets the EP sweep's two extra streams right away (created together with the first two they land on
+    // hardware queues of their own: made later, on first use, a sweep at n = 4096 ran at 104 instead of 180 sweeps/s); helper
+    // contexts (batched LML workers, concurrent small EP runs) do without: every stream competes for the few hardware queues.
+    if (e == hipSuccess && !g_child_ctx && gpi_ctx_ep_streams(ctx) != GP_OK) e = hipErrorInvalidValue;
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_a, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_b, hipEventDisableTiming);
     if (const char *la = getenv("GPCORE_LOOKAHEAD")) ctx->lookahead = atoi(la) != 0 ? 1 : 0;
@@ -1379,7 +1401,10 @@ extern "C" gp_status gp_lml_grad_rbf_batched(gp_ctx *ctx, const double *X, int n
     ctx_ext *x = ext_of(ctx);
     while ((int)x->children.size() < nw - 1) {
         gp_ctx *c = nullptr;
-        if (gp_ctx_create(ctx->device, nullptr, &c) != GP_OK) break;
+        g_child_ctx = true;
+        const gp_status cst = gp_ctx_create(ctx->device, nullptr, &c);
+        g_child_ctx = false;
+        if (cst != GP_OK) break;
         x->children.push_back(c);
     }
     nw = std::min(nw, (int)x->children.size() + 1);

@@ -912,6 +912,7 @@ gp_status gp_ep_sweep(gp_ep *ep, int nsweeps, double *tau, double *nu, int *info
     // GPCORE_EP_PIPELINE: 1 / 0 force the streamed refactorisation on / off; default on above np = 1024 (sweeps/s with / without
     // it: n = 1024 552 / 592, n = 2048 382 / 265, n = 4096 162 / 102, n = 8192 29.1 / 27.2)
     const bool pipe = overlap && np >= 2 * GP_NB && [np] { const char *e = getenv("GPCORE_EP_PIPELINE"); return e ? atoi(e) != 0 : np > 1024; }();
+    if (pipe) GP_TRY(gpi_ctx_ep_streams(ctx));
     hipStream_t s2 = ctx->side, s3 = ctx->side2, s4 = ctx->side3;
     // The link between two block kernels as ONE launch (gpk_ep_link) or as panel solve + tile update on 2 + 36 workgroups: alone the two
     // launches are faster (the single workgroup is bound by one CU's matrix pipe: n = 4096 end-of-sweep form 106.9 vs 103.3 sweeps/s),

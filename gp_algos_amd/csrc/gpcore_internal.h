@@ -171,6 +171,7 @@ gp_status gpi_model_alloc(gp_ctx *ctx, int n, int d, bool has_x, gp_model **out)
 gp_status gpi_lbfgs_maximize(gp_ctx *ctx, int P, int nparams, const double *theta0, int max_iter, int history, int NC,
                              const std::function<gp_status(const double *, int, double *, double *, int *)> &evaluate,
                              double *theta_out, double *f_out, int *iters_out, int *evals_out);
+gp_status gpi_ctx_ep_streams(gp_ctx *ctx);   // side2 / side3, created on first use
 void gpi_chol_blocked(gp_ctx *ctx, double *A, int np, int lda, double *dinv, int extra);
 // one 128-column step (diagonal block k0) of the same two-level factorisation on stream s, for callers that feed the columns
 // one block at a time: diagonal factor, panel solve, in-panel update, and the K = OUTER trailing update when k0 closes an outer panel
