@@ -6,9 +6,16 @@ One "step" = one pass of the hot path over one batch of synthetic input (config 
     -> posterior mean + variance at m=65536 test points                  (GpPredictor.predict, diag variance)
 with X, y, X* already resident in HBM.  value = test points / second over the whole job.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): the path shards over test points --
-every rank fits the same model redundantly (no data-path collective; SURVEY.md 8e: refit 0.05 s vs
-broadcasting 0.5 GB of L) and predicts its own m points; weak scaling, value = N*m / max-rank time.
+N > 1, one rank per GPU.  Two ways in, same ranks either way:
+  * under an external launcher (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`): RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* come from the environment;
+  * plain `python bench.py --gpus N` with no WORLD_SIZE in the environment: this process starts the N ranks itself as child
+    processes (self_launch) BEFORE anything touches the GPU, never initialises the GPU itself and exits with their status.
+The path shards over test points -- every rank fits the same model redundantly (no data-path collective; SURVEY.md 8e: refit
+7 ms vs broadcasting 0.5 GB of L) and predicts its own m points; weak scaling, value = N*m / max-rank time; the posterior of all
+N*m points is assembled on every rank by one all_gather per step.  The same JSON line also carries the north-star's own scaling
+workload as `c3_sharded`: LML + gradient over 64 settings at n = 4096 sharded 64/N per GPU (strong scaling, settings/s, per-rank
+seconds, and the C-ABI's own RCCL path gp_dist_lml_grad_batched checked against it).
 torch is used for rendezvous/barrier/max-reduce only; all compute goes through libgpcore.so.
 """
 import argparse
@@ -41,29 +48,33 @@ def host_cores():
     return max(1, min(n, int(os.environ.get("GPCORE_CPU_THREADS", "64"))))
 
 
-def cpu_baseline(p, L_host, alpha_host, m_total, budget_pts=256):
+def cpu_baseline(p, L_host, alpha_host, m_total, budget_pts=256, fit_full_size=False):
     """The stated CPU baseline (`cpu_ref`): oracle/gp_oracle.c -- the 1-thread restatement of the reference's
     loops -- timed on a BOUNDED sample of the same workload.  Fit (Gram + unblocked Cholesky + two substitution solves,
     GpPredictor.preComputeComponents) is timed at n = 1024, 2048, 4096 on leading subsets of the same X, y and extrapolated
-    to the full n by a least-squares cubic a n^3 + b n^2 (n = 8192 itself would take minutes); predict (cross-Gram + scalar
-    forward substitution + variance per point) is timed at the full n against the real factor on a few of the test points.
-    value = points/s of a whole fit + predict step, the benchmark's metric."""
+    to the full n by the power law through the last two sizes, t(n) = t(4096) (n / 4096)^p with p = log2(t(4096) / t(2048))
+    -- the measured exponent, printed in the record: the row-walking substitution and the unblocked Cholesky fall out of
+    cache as n grows, so the growth per doubling is well above the 8x of a cubic (7x then 13x measured) and a cubic fit
+    would understate n = 8192.  `--cpu-fit-full` times the fit at the full n instead (about a minute).  Predict (cross-Gram +
+    scalar forward substitution + variance per point) is timed at the full n against the real factor on a few of the test
+    points.  value = points/s of a whole fit + predict step, the benchmark's metric."""
     from oracle import gp_oracle as orc
     orc.build()
     n = p["X"].shape[0]
     sizes = [s_ for s_ in (1024, 2048, 4096) if s_ <= n]
+    if fit_full_size and n not in sizes:
+        sizes.append(n)
     fit_s = []
     for s_ in sizes:
         Xs_, ys_ = np.asfortranarray(p["X"][:s_]), np.ascontiguousarray(p["y"][:s_])
         t0 = time.perf_counter()
         orc.fit(Xs_, ys_, p["theta"])
         fit_s.append(time.perf_counter() - t0)
+    expo = float(np.log(fit_s[-1] / fit_s[-2]) / np.log(sizes[-1] / sizes[-2])) if len(sizes) >= 2 else 3.0
     if sizes and sizes[-1] == n:
         fit_full, extrapolated = fit_s[-1], False
     else:
-        A = np.array([[float(s_) ** 3, float(s_) ** 2] for s_ in sizes])
-        coef, *_ = np.linalg.lstsq(A, np.array(fit_s), rcond=None)
-        fit_full, extrapolated = float(coef[0] * float(n) ** 3 + coef[1] * float(n) ** 2), True
+        fit_full, extrapolated = float(fit_s[-1] * (float(n) / sizes[-1]) ** expo), True
     xs = np.asfortranarray(p["Xs"][:2])
     t0 = time.perf_counter()
     orc.predict(p["X"], p["theta"], L_host, alpha_host, xs)
@@ -75,12 +86,15 @@ def cpu_baseline(p, L_host, alpha_host, m_total, budget_pts=256):
     dt = time.perf_counter() - t0
     step_s = fit_full + m_total * dt / k
     return dict(value=m_total / step_s, unit="points/s", cores=1, kind="port", extrapolated=extrapolated,
-                fit_s_measured={str(s_): t for s_, t in zip(sizes, fit_s)}, fit_s_at_n=fit_full, predict_points_per_s=k / dt,
-                step_s_at_n=step_s,
-                sample="oracle/gp_oracle.c, 1 thread: fit timed at n=%s on leading subsets of the same X, y and extrapolated to "
-                       "n=%d by a least-squares a*n^3+b*n^2; predict timed on %d of the %d test points at the full n=%d against the "
-                       "factor of the GPU fit; value = %d points / (fit + %d points at the measured rate)"
-                       % ("/".join(map(str, sizes)), n, k, m_total, n, m_total, m_total)), mean, var, k
+                fit_s_measured={str(s_): t for s_, t in zip(sizes, fit_s)}, fit_growth_exponent_last_doubling=expo,
+                fit_s_at_n=fit_full, predict_points_per_s=k / dt, step_s_at_n=step_s,
+                sample="oracle/gp_oracle.c, 1 thread: fit timed at n=%s on leading subsets of the same X, y%s; predict timed on %d of "
+                       "the %d test points at the full n=%d against the factor of the GPU fit; value = %d points / (fit + %d "
+                       "points at the measured rate)"
+                       % ("/".join(map(str, sizes)),
+                          " and extrapolated to n=%d by the power law through the last two sizes (exponent %.2f)" % (n, expo)
+                          if extrapolated else " (the full n included: nothing extrapolated)",
+                          k, m_total, n, m_total, m_total)), mean, var, k
 
 
 def _cholesky_block(n, t_fit, t_fit_serial, o_k, o_ms, o_work, p_k, p_ms, p_work):
@@ -139,9 +153,7 @@ def run_secondary(args):
     from gp_algos_amd import _lib as L, synth
     from gp_algos_amd.core import Context, EpClassifierState
     ctx = Context(local_rank)
-    names = {L.GP_PROF_GEMM: "gemm_nt_f64_kernel<0,*> (general product: T = L^-T updates / rank-128 EP updates / posterior steps)",
-             L.GP_PROF_SYRK: "gemm_nt_f64_kernel<1,*> (lower-trapezoid product: Cholesky K=512 trailing update, T T^T, Sigma = K - Vt Vt^T)",
-             L.GP_PROF_PANEL_UPD: "gemm_nt_f64_kernel<1,1> (K = 128 in-panel update)"}
+    names = _class_names(L)
     prof_mask = (1 << L.GP_PROF_GEMM) | (1 << L.GP_PROF_SYRK) | (1 << L.GP_PROF_PANEL_UPD)
 
     def fence():
@@ -152,74 +164,21 @@ def run_secondary(args):
 
     if args.workload == "c3":
         n = args.n if args.n != 8192 else 4096
-        P = args.d + 2
-        p = synth.config_c3(n, args.d)
-        B = p["thetas"].shape[0]
-        lo, hi = gdist.shard_range(B, rank, world)
-        state = {}
-
-        def evaluate(th):                                    # this rank's settings on this rank's GPU
-            lml_, grad_, info_ = ctx.lml_grad_batched(p["X"], p["y"], th)
-            state["info"] = info_
-            return lml_, grad_
-
-        def step():                                          # settings sharded b -> rank b // ceil(B / world), results by ONE all_gather
-            return gdist.lml_grad_sharded(evaluate, p["thetas"], device=coll_dev)
-
-        for _ in range(args.warmup):
-            step()                                           # same shapes as the timed steps: workspaces are allocated here
-        fence()
-        ctx.profile(prof_mask)
-        t_rank = time.perf_counter()
-        for _ in range(args.steps):
-            lml, grad = step()
-        fence()
-        t_rank = time.perf_counter() - t_rank
-        ctx.profile(0)
-        dt = gdist.max_over_ranks(t_rank, device=coll_dev)
-        times = gdist.all_gather_rows(np.array([[t_rank]]), world, device=coll_dev) if world > 1 else np.array([[t_rank]])
-        roof = _roofline_from_profile(ctx, L, (L.GP_PROF_GEMM, L.GP_PROF_SYRK, L.GP_PROF_PANEL_UPD), names)
-        # spot check outside the timed region: one setting alone (count = 1 forms of every step) against its lockstep result
-        b0 = lo if hi > lo else 0
-        one, gone, _ = ctx.lml_grad_batched(p["X"], p["y"], p["thetas"][b0:b0 + 1])
-        chk = float(max(abs(one[0] - lml[b0]) / abs(one[0]), np.max(np.abs(gone[0] - grad[b0])) / np.max(np.abs(gone[0]))))
-        # The same sharded evaluation through the C-ABI's own RCCL entry point (gp_dist_lml_grad_batched: what a Scala host
-        # calls), outside the timed region, against the torch.distributed result: only on real multi-GPU runs
-        cabi = None
-        if world > 1 and backend == "nccl":
-            try:
-                import torch.distributed as tdist
-                from gp_algos_amd.core import DistGroup
-
-                def exchange(ident):
-                    obj = [ident]
-                    tdist.broadcast_object_list(obj, src=0, device=torch.device("cuda", local_rank))
-                    return obj[0]
-
-                grp = DistGroup(ctx, rank, world, exchange)
-                l2, g2, _ = grp.lml_grad_batched(p["X"], p["y"], p["thetas"])
-                cabi = bool(np.array_equal(l2, lml) and np.array_equal(g2, grad))
-                grp.close()
-            except Exception as e:   # reported, never fatal for the benchmark line
-                cabi = "failed: %s" % e
+        c3 = measure_c3(ctx, n, args.d, args.steps, args.warmup, rank, world, local_rank, backend, coll_dev, names)
         if rank == 0:
-            # n^3/3 (potrf) + 2 n^3/3 (K^-1 from L) + 2 n^2 (alpha) + P 2 n^2 (fused traces) per setting
-            flops = float(n) ** 3 + (2.0 + 2.0 * P) * n * n
-            tf = flops * B * args.steps / dt / 1e12
-            print(json.dumps({"metric": "LML+gradient settings/sec at n=%d fp64, P=%d" % (n, P), "value": B * args.steps / dt,
+            P, B = args.d + 2, c3["B"]
+            print(json.dumps({"metric": "LML+gradient settings/sec at n=%d fp64, P=%d" % (n, P), "value": c3["settings_per_s"],
                               "unit": "settings/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                              "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                              "ms_per_step": c3["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                               "dtype": "f64", "data": "synthetic",
-                              "config": {"workload": "C3: log-marginal-likelihood + gradient over %d hyper-parameter settings, n=%d d=%d, settings "
-                                                     "sharded %d per GPU (b -> rank b // %d), every rank holds X and y, results assembled on "
-                                                     "every rank by one all_gather of (B/G) x (1+P) doubles per step"
-                                                     % (B, n, args.d, hi - lo, -(-B // world)), "B": B, "n": n,
-                                         "timed_region": "per step: upload of X, y (%d KB) + all settings of this rank + the all_gather" % ((n * args.d + n) * 8 // 1024)},
-                              "algorithmic_tflops_total": tf, "algorithmic_tflops_per_gpu": tf / world,
-                              "frac_of_fp64_mfma_peak_per_gpu": tf / world / PEAK_FP64_MFMA_TFLOPS,
-                              "roofline": roof, "per_rank_seconds": [float(t) for t in times[:, 0]],
-                              "lml_first": float(lml[0]), "lml_last": float(lml[-1]), "all_finite": bool(np.all(np.isfinite(lml)) and np.all(np.isfinite(grad))),
-                              "lockstep_vs_single_setting_max_rel": chk, "c_abi_rccl_allgather_matches": cabi}), flush=True)
+                              "config": {"workload": c3["workload"], "B": B, "n": n, "timed_region": c3["timed_region"]},
+                              "algorithmic_tflops_total": c3["algorithmic_tflops_total"],
+                              "algorithmic_tflops_per_gpu": c3["algorithmic_tflops_per_gpu"],
+                              "frac_of_fp64_mfma_peak_per_gpu": c3["frac_of_fp64_mfma_peak_per_gpu"],
+                              "roofline": c3["roofline"], "per_rank_seconds": c3["per_rank_seconds"],
+                              "lml_first": c3["lml_first"], "lml_last": c3["lml_last"], "all_finite": c3["all_finite"],
+                              "lockstep_vs_single_setting_max_rel": c3["lockstep_vs_single_setting_max_rel"],
+                              "c_abi_rccl_allgather_matches": c3["c_abi_rccl_allgather_matches"]}), flush=True)
     elif args.workload == "c5":
         import ctypes as C
         n = args.n if args.n != 8192 else 32768
@@ -317,6 +276,126 @@ def run_secondary(args):
     gdist.barrier()
 
 
+def _class_names(L):
+    return {L.GP_PROF_GEMM: "gemm_nt_f64_kernel<0,*> (general product: T = L^-T updates / rank-128 EP updates / posterior steps)",
+            L.GP_PROF_SYRK: "gemm_nt_f64_kernel<1,*> (lower-trapezoid product: Cholesky K=512 trailing update, T T^T, Sigma = K - Vt Vt^T)",
+            L.GP_PROF_PANEL_UPD: "gemm_nt_f64_kernel<1,1> (K = 128 in-panel update)"}
+
+
+def measure_c3(ctx, n, d, steps, warmup, rank, world, local_rank, backend, coll_dev, names):
+    """BASELINE config C3, the north-star's scaling workload: LML + gradient over the 64 settings of the 4 x 4 x 4 grid at
+    n = 4096, settings sharded b -> rank b // ceil(B / world) (8 per GPU at 8 GPUs), every rank holds X and y, results
+    assembled on every rank by ONE all_gather per step (gp_algos_amd/dist.py lml_grad_sharded; strong scaling).  Timed like the
+    headline: barrier + device sync on both sides, max over ranks.  Outside the timed region the same sharded evaluation runs
+    through the C-ABI's own RCCL entry point (gp_dist_lml_grad_batched -- what a Scala host calls) and is compared with it.
+    Returns the figures on every rank."""
+    import torch
+    from gp_algos_amd import _lib as L, dist as gdist, synth
+    P = d + 2
+    p = synth.config_c3(n, d)
+    B = p["thetas"].shape[0]
+    lo, hi = gdist.shard_range(B, rank, world)
+
+    def fence():
+        ctx.sync()
+        torch.cuda.synchronize()
+        gdist.barrier()
+        torch.cuda.synchronize()
+
+    def evaluate(th):                                    # this rank's settings on this rank's GPU
+        lml_, grad_, _ = ctx.lml_grad_batched(p["X"], p["y"], th)
+        return lml_, grad_
+
+    def step():                                          # results by ONE all_gather (after the status exchange)
+        return gdist.lml_grad_sharded(evaluate, p["thetas"], device=coll_dev)
+
+    for _ in range(warmup):
+        step()                                           # same shapes as the timed steps: workspaces are allocated here
+    fence()
+    prof_mask = (1 << L.GP_PROF_GEMM) | (1 << L.GP_PROF_SYRK) | (1 << L.GP_PROF_PANEL_UPD)
+    ctx.profile(prof_mask)
+    t_rank = time.perf_counter()
+    for _ in range(steps):
+        lml, grad = step()
+    fence()
+    t_rank = time.perf_counter() - t_rank
+    ctx.profile(0)
+    dt = gdist.max_over_ranks(t_rank, device=coll_dev)
+    times = gdist.all_gather_rows(np.array([[t_rank]]), world, device=coll_dev) if world > 1 else np.array([[t_rank]])
+    roof = _roofline_from_profile(ctx, L, (L.GP_PROF_GEMM, L.GP_PROF_SYRK, L.GP_PROF_PANEL_UPD), names)
+    # spot check outside the timed region: one setting alone (count = 1 forms of every step) against its lockstep result
+    b0 = lo if hi > lo else 0
+    one, gone, _ = ctx.lml_grad_batched(p["X"], p["y"], p["thetas"][b0:b0 + 1])
+    chk = float(max(abs(one[0] - lml[b0]) / abs(one[0]), np.max(np.abs(gone[0] - grad[b0])) / np.max(np.abs(gone[0]))))
+    cabi = None
+    if world > 1 and backend == "nccl":
+        try:
+            import torch.distributed as tdist
+            from gp_algos_amd.core import DistGroup
+
+            def exchange(ident):
+                obj = [ident]
+                tdist.broadcast_object_list(obj, src=0, device=torch.device("cuda", local_rank))
+                return obj[0]
+
+            grp = DistGroup(ctx, rank, world, exchange)
+            l2, g2, _ = grp.lml_grad_batched(p["X"], p["y"], p["thetas"])
+            cabi = bool(np.array_equal(l2, lml) and np.array_equal(g2, grad))
+            grp.close()
+        except Exception as e:   # reported, never fatal for the benchmark line
+            cabi = "failed: %s" % e
+    # SURVEY.md 8(d): n^3/3 (potrf) + 2 n^3/3 (K^-1 from L) + 2 n^2 (alpha) + P 2 n^2 (fused traces) per setting
+    flops = float(n) ** 3 + (2.0 + 2.0 * P) * n * n
+    tf = flops * B * steps / dt / 1e12
+    return {"settings_per_s": B * steps / dt, "unit": "settings/s", "scaling": "strong", "n_gpus": world, "steps": steps,
+            "warmup": warmup, "ms_per_step": dt / steps * 1e3, "B": B, "n": n, "settings_per_gpu": hi - lo,
+            "workload": "C3: log-marginal-likelihood + gradient over %d hyper-parameter settings, n=%d d=%d, settings sharded %d per GPU "
+                        "(b -> rank b // %d), every rank holds X and y, results assembled on every rank by one all_gather of "
+                        "(B/G) x (1+P) doubles per step" % (B, n, d, -(-B // world), -(-B // world)),
+            "timed_region": "per step: upload of X, y (%d KB) + all settings of this rank + status exchange + the all_gather" % ((n * d + n) * 8 // 1024),
+            "algorithmic_tflops_total": tf, "algorithmic_tflops_per_gpu": tf / world,
+            "frac_of_fp64_mfma_peak_per_gpu": tf / world / PEAK_FP64_MFMA_TFLOPS, "roofline": roof,
+            "per_rank_seconds": [float(t) for t in times[:, 0]], "lml_first": float(lml[0]), "lml_last": float(lml[-1]),
+            "all_finite": bool(np.all(np.isfinite(lml)) and np.all(np.isfinite(grad))),
+            "lockstep_vs_single_setting_max_rel": chk, "c_abi_rccl_allgather_matches": cabi}
+
+
+def self_launch(gpus, argv, dry=False):
+    """`bench.py --gpus N` with no launcher around it: start the N ranks as child processes of THIS process -- which has not
+    touched the GPU and never will (no torch import, no HIP call, no libgpcore.so) -- with RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR=127.0.0.1 / MASTER_PORT in their environment, wait for them and return the worst exit status.  Rank 0 inherits
+    stdout (it prints the one JSON line); the other ranks' stdout goes to stderr.  If a rank dies, the rest are given 30 s to
+    follow (their collectives fail or time out) and are then terminated by PID."""
+    import socket
+    import subprocess
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    procs = []
+    for r in range(gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(gpus), LOCAL_WORLD_SIZE=str(gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GPCORE_BENCH_SELF_LAUNCHED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if (r == 0 or dry) else sys.stderr))
+    rc, deadline = 0, None
+    while procs:
+        for pr in list(procs):
+            code = pr.poll()
+            if code is None:
+                continue
+            procs.remove(pr)
+            if code != 0:
+                rc = rc or (code if code > 0 else 128 - code)
+                deadline = deadline or time.time() + 30.0
+        if procs and deadline and time.time() > deadline:
+            for pr in procs:
+                pr.terminate()
+            deadline = time.time() + 10.0
+        time.sleep(0.05)
+    return rc
+
+
 PMC_SUMMARY = "r02_c_pmc_c2_summary.json"
 DOMINANT_KERNEL = "gemm_fused_kernel<0,0,1,8>"
 
@@ -376,7 +455,24 @@ def main():
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5"],
                     help="c2 (default, the BASELINE.json metric): fit + posterior; c3: batched LML+gradient over 64 settings; "
                          "c4: EP classification sweeps; c5: n=32768 fit once, then 10^6/8 test-point variances per GPU per step")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="ranks print their RANK / LOCAL_RANK / WORLD_SIZE as one JSON line and exit without touching the GPU "
+                         "(the launch path of --gpus N, testable on a host without a GPU)")
+    ap.add_argument("--cpu-fit-full", action="store_true", help="cpu_baseline: time the oracle's fit at the full n (about a minute)")
+    ap.add_argument("--no-c3", action="store_true", help="leave the c3_sharded block out of the c2 line")
     args = ap.parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher around us: become one.  Nothing above this line imports torch or loads libgpcore.so.
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:], dry=args.dry_launch))
+    if args.dry_launch:
+        if os.environ.get("GPCORE_BENCH_DRY_FAIL_RANK") == os.environ.get("RANK", "0"):
+            raise SystemExit(3)                  # test hook: one rank dies, the launcher must report it
+        print(json.dumps({"dry_launch": True, "rank": int(os.environ.get("RANK", "0")), "local_rank": int(os.environ.get("LOCAL_RANK", "0")),
+                          "world": int(os.environ.get("WORLD_SIZE", "1")), "master": "%s:%s" % (os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT")),
+                          "self_launched": os.environ.get("GPCORE_BENCH_SELF_LAUNCHED") == "1"}), flush=True)
+        return
+    if "WORLD_SIZE" in os.environ and args.gpus != int(os.environ["WORLD_SIZE"]):
+        print("bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks; the launcher wins" % (args.gpus, os.environ["WORLD_SIZE"]), file=sys.stderr)
     if args.workload != "c2":
         return run_secondary(args)
 
@@ -488,6 +584,12 @@ def main():
     o_k, o_ms, o_work = ctx.profile_read(L.GP_PROF_SYRK)
     p_k, p_ms, p_work = ctx.profile_read(L.GP_PROF_PANEL_UPD)
 
+    # The north-star's scaling workload in the same line: C3 sharded over the ranks (every rank takes part: collectives inside)
+    c3 = None
+    if not args.no_c3:
+        c3 = measure_c3(ctx, 4096, d, max(2, min(args.steps, 5)), 1, rank, world, local_rank, backend,
+                        "cuda" if backend == "nccl" else "cpu", _class_names(L))
+
     out = None
     if rank == 0:
         # HBM traffic per launch of the dominant kernel: PMC counters cannot be read from inside the process, so the
@@ -532,6 +634,7 @@ def main():
             "gram": {"GBps": r_work / (r_ms * 1e-3) / 1e9 if r_ms > 0 else 0.0, "frac_of_hbm_peak": (r_work / (r_ms * 1e-3) / 1e9) / PEAK_HBM_GBS if r_ms > 0 else 0.0},
             "predict_only_points_per_s": m / t_pred, "predict_ms": t_pred * 1e3,
             "mfma_f64_probe_tflops": probe,
+            "c3_sharded": c3,
         }
     # CPU baseline on rank 0 at N=1 only
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -539,7 +642,7 @@ def main():
         ctx.check(lib.gp_model_get(h, L.GP_GET_L, L.dptr(Lh), n))
         ah = np.zeros(n)
         ctx.check(lib.gp_model_get(h, L.GP_GET_ALPHA, L.dptr(ah), n))
-        base, cmean, cvar, kk = cpu_baseline(p, Lh, ah, m)
+        base, cmean, cvar, kk = cpu_baseline(p, Lh, ah, m, fit_full_size=args.cpu_fit_full)
         gmean = ctx.download(dmean, (m,))[:kk]
         gvar = ctx.download(dvar, (m,))[:kk]
         base["max_abs_dmean_vs_gpu"] = float(np.max(np.abs(gmean - cmean)))

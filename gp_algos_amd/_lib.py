@@ -8,7 +8,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgpcore.so")
 
-GP_OK, GP_EINVAL, GP_ENOTPD, GP_ENOMEM, GP_EHIP, GP_ERANGE, GP_ERCCL = range(7)
+GP_OK, GP_EINVAL, GP_ENOTPD, GP_ENOMEM, GP_EHIP, GP_ERANGE, GP_ERCCL, GP_EPEER = range(8)
 GP_DIST_ID_BYTES = 128
 GP_LOWER, GP_FULL = 0, 1
 GP_GET_L, GP_GET_ALPHA, GP_GET_LML = 0, 1, 2
@@ -90,6 +90,8 @@ SIGNATURES = {
     "gp_dist_unique_id": (_i, [_vp, C.c_char_p]),
     "gp_dist_init": (_i, [_vp, C.c_char_p, _i, _i, C.POINTER(_vp)]),
     "gp_dist_destroy": (None, [_vp]),
+    "gp_dist_status_scan": (_i, [_dp, _i, _i, _ip]),
+    "gp_dist_inject_failure": (_i, [_vp]),
     "gp_dist_shard": (_i, [_vp, _i, _ip, _ip]),
     "gp_dist_lml_grad_batched": (_i, [_vp, _dp, _i, _i, _i, _dp, _dp, _i, _i, _d, _dp, _dp, _ip]),
     "gp_dist_predict": (_i, [_vp, _vp, _dp, _i, _i, _dp, _dp]),
@@ -103,6 +105,10 @@ class GpCoreError(RuntimeError):
         super().__init__("gpcore status %d: %s" % (status, msg))
         self.status = status
         self.info = info
+
+
+class PeerFailure(GpCoreError):
+    """gp_dist_* / dist.py: another rank of the group failed; nothing was exchanged and this rank is intact (GP_EPEER)."""
 
 
 class NotPositiveDefinite(GpCoreError):

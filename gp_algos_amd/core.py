@@ -39,6 +39,8 @@ class Context:
             raise ValueError(msg)
         if st == L.GP_ERANGE:
             raise IndexError(msg)
+        if st == L.GP_EPEER:
+            raise L.PeerFailure(st, msg, info)
         raise L.GpCoreError(st, msg, info)
 
     def trim(self):
@@ -497,6 +499,10 @@ class DistGroup:
         self.h = None
 
     __del__ = close
+
+    def inject_failure(self):
+        """Test hook (gp_dist_inject_failure): this rank's next collective call fails locally with GP_ENOMEM."""
+        self.ctx.check(self.ctx._lib.gp_dist_inject_failure(self.h))
 
     def shard(self, total):
         lo, hi = C.c_int(), C.c_int()

@@ -3,7 +3,10 @@
 // The hot path shards over INDEPENDENT units only -- hyper-parameter settings (config C3:
 // GpPredictor.logLikelihoodWithDerivatives evaluated by obtainOptimalHyperParams / the mesh evaluator,
 // gp/regression/GpPredictor.scala:60-80,126-142) and test points (config C5: GpPredictor.predict :24-43) -- so the only
-// collective on the data path is ONE ncclAllGather of the per-rank results; the Cholesky itself stays single-GPU.
+// collective on the data path is ONE ncclAllGather of the per-rank results (preceded by an all-gather of one status word per
+// rank, so that a rank whose local part failed -- GP_ENOMEM, GP_EHIP, a bad argument only it sees -- cannot leave its peers
+// blocked inside the collective: every rank learns of the failure and returns, the failing rank with its own status, the
+// others with GP_EPEER); the Cholesky itself stays single-GPU.
 // Every rank passes the SAME inputs, evaluates the contiguous slice  [rank * ceil(U/G), ...)  of the U units on its own
 // device and receives the assembled result.  Message sizes: (B/G) x (2 + nparams) doubles (C3: 8 x 12 x 8 B = 768 B per
 // rank) or 2 m/G doubles (C5: 2 MB per rank) -- far below one xGMI link's 153 GB/s; no reduction, no ring of large tensors.
@@ -65,6 +68,8 @@ struct gp_dist {
     int rank = 0, world = 1;
     double *send = nullptr, *recv = nullptr;   // device staging of the all-gather
     size_t cap = 0;                            // doubles per rank the staging buffers hold
+    double *st_send = nullptr, *st_recv = nullptr;   // status words (1 per rank), allocated with the communicator
+    int fail_next = 0;                         // fault injection for the tests (gp_dist_inject_failure): next call fails locally
 };
 
 #define GP_RCCL(ctx, call) do { int r_ = (call); if (r_ != 0) { \
@@ -87,10 +92,28 @@ gp_status dist_reserve(gp_dist *d, size_t per_rank) {
     return GP_OK;
 }
 
-// host slice (count doubles, zero-padded to per_rank) -> every rank's slices, rank-major, on the host
+// Every rank's status word to every rank, BEFORE the payload collective.  `local` is what this rank's own part returned
+// (evaluation, staging allocation).  Uses only buffers that exist since gp_dist_init, so it cannot fail locally short of a
+// dead device or communicator -- and then RCCL's own abort handling is what the peers see.  All ranks return non-zero or
+// all return GP_OK: nobody enters the payload all-gather alone.
+gp_status dist_agree(gp_dist *d, gp_status local) {
+    gp_ctx *ctx = d->ctx;
+    const double mine = (double)(int)local;
+    std::vector<double> all((size_t)d->world, 0.0);
+    GP_HIP(ctx, hipMemcpyAsync(d->st_send, &mine, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    GP_RCCL(ctx, rccl().AllGather(d->st_send, d->st_recv, 1, RCCL_FLOAT64, d->comm, ctx->stream));
+    GP_HIP(ctx, hipMemcpyAsync(all.data(), d->st_recv, sizeof(double) * all.size(), hipMemcpyDeviceToHost, ctx->stream));
+    GP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    int bad = -1;
+    const gp_status s = gp_dist_status_scan(all.data(), d->world, d->rank, &bad);
+    if (s == GP_EPEER) GP_SET_ERR(ctx, "rank %d of the group failed with status %d; no result was exchanged", bad, (int)all[(size_t)bad]);
+    return s;
+}
+
+// host slice (count doubles, zero-padded to per_rank) -> every rank's slices, rank-major, on the host.  The caller has
+// reserved the staging (dist_reserve) and agreed with its peers (dist_agree) before.
 gp_status dist_allgather(gp_dist *d, const double *mine, size_t count, size_t per_rank, std::vector<double> &all) {
     gp_ctx *ctx = d->ctx;
-    GP_TRY(dist_reserve(d, per_rank));
     std::vector<double> pad(per_rank, 0.0);
     std::copy(mine, mine + count, pad.begin());
     GP_HIP(ctx, hipMemcpyAsync(d->send, pad.data(), sizeof(double) * per_rank, hipMemcpyHostToDevice, ctx->stream));
@@ -132,6 +155,13 @@ gp_status gp_dist_init(gp_ctx *ctx, const unsigned char *id, int rank, int world
         delete d;
         return GP_ERCCL;
     }
+    hipError_t e = hipMalloc(&d->st_send, sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&d->st_recv, sizeof(double) * (size_t)world);
+    if (e != hipSuccess) {
+        GP_SET_ERR(ctx, "hipMalloc of the status words failed: %s", hipGetErrorString(e));
+        gp_dist_destroy(d);
+        return GP_ENOMEM;
+    }
     *out = d;
     return GP_OK;
 }
@@ -142,7 +172,26 @@ void gp_dist_destroy(gp_dist *d) {
     if (d->comm) (void)rccl().CommDestroy(d->comm);
     if (d->send) (void)hipFree(d->send);
     if (d->recv) (void)hipFree(d->recv);
+    if (d->st_send) (void)hipFree(d->st_send);
+    if (d->st_recv) (void)hipFree(d->st_recv);
     delete d;
+}
+
+gp_status gp_dist_status_scan(const double *status, int world, int rank, int *bad_rank) {
+    if (!status || world < 1 || rank < 0 || rank >= world) return GP_EINVAL;
+    int first = -1;
+    for (int r = 0; r < world; ++r)
+        if (status[r] != 0.0) { first = r; break; }
+    if (bad_rank) *bad_rank = first;
+    if (first < 0) return GP_OK;
+    if (status[rank] != 0.0) { if (bad_rank) *bad_rank = rank; return (gp_status)(int)status[rank]; }
+    return GP_EPEER;
+}
+
+gp_status gp_dist_inject_failure(gp_dist *d) {
+    if (!d) return GP_EINVAL;
+    d->fail_next = 1;
+    return GP_OK;
 }
 
 gp_status gp_dist_shard(const gp_dist *d, int total, int *lo, int *hi) {
@@ -165,8 +214,12 @@ gp_status gp_dist_lml_grad_batched(gp_dist *d, const double *X, int n, int dd, i
     const int mine = hi - lo, W = 2 + nparams;   // per setting: lml | info | grad[nparams]
     std::vector<double> l(std::max(mine, 1)), g((size_t)std::max(mine, 1) * std::max(nparams, 1));
     std::vector<int> inf(std::max(mine, 1), 0);
-    if (mine > 0)
-        GP_TRY(gp_lml_grad_rbf_batched(ctx, X, n, dd, ldx, y, thetas + (size_t)lo * P, mine, nparams, sigma_noise, l.data(), g.data(), inf.data()));
+    // nothing between here and dist_agree returns: a rank that fails locally still takes part in the status exchange
+    gp_status local = dist_reserve(d, (size_t)per * (2 + nparams));
+    if (local == GP_OK && mine > 0)
+        local = gp_lml_grad_rbf_batched(ctx, X, n, dd, ldx, y, thetas + (size_t)lo * P, mine, nparams, sigma_noise, l.data(), g.data(), inf.data());
+    if (local == GP_OK && d->fail_next) local = GP_ENOMEM, d->fail_next = 0;
+    GP_TRY(dist_agree(d, local));
     std::vector<double> pack((size_t)std::max(mine, 1) * W, 0.0), all;
     for (int b = 0; b < mine; ++b) {
         pack[(size_t)b * W] = l[b];
@@ -195,7 +248,10 @@ gp_status gp_dist_predict(gp_dist *d, gp_model *model, const double *Xs, int m, 
     GP_TRY(gp_dist_shard(d, m, &lo, &hi));
     const int mine = hi - lo;
     std::vector<double> pack((size_t)2 * std::max(mine, 1), 0.0), all;
-    if (mine > 0) GP_TRY(gp_predict(model, Xs + lo, mine, ldxs, pack.data(), pack.data() + mine, nullptr, 0));
+    gp_status local = dist_reserve(d, (size_t)2 * per);
+    if (local == GP_OK && mine > 0) local = gp_predict(model, Xs + lo, mine, ldxs, pack.data(), pack.data() + mine, nullptr, 0);
+    if (local == GP_OK && d->fail_next) local = GP_ENOMEM, d->fail_next = 0;
+    GP_TRY(dist_agree(d, local));
     // interleave as [mean slice | var slice] per rank: two contiguous runs of `mine` doubles, padded to `per` each
     std::vector<double> slot((size_t)2 * per, 0.0);
     std::copy(pack.begin(), pack.begin() + mine, slot.begin());

@@ -52,6 +52,48 @@ def max_over_ranks(value, device="cpu"):
     return float(t.item())
 
 
+class PeerFailure(RuntimeError):
+    """Another rank's local evaluation failed; nothing was exchanged (the torch.distributed form of GP_EPEER)."""
+
+    def __init__(self, bad_rank, status):
+        super().__init__("rank %d of the group failed with status %d; no result was exchanged" % (bad_rank, status))
+        self.bad_rank, self.status = bad_rank, status
+
+
+def status_scan(status, rank):
+    """gp_dist_status_scan's rule on a vector of per-rank status words: (0, -1) if every rank is fine, (own status, rank)
+    if this rank failed, else (GP_EPEER = 7, first failing rank)."""
+    status = [int(s) for s in status]
+    bad = next((r for r, s in enumerate(status) if s != 0), -1)
+    if bad < 0:
+        return 0, -1
+    if status[rank] != 0:
+        return status[rank], rank
+    return 7, bad
+
+
+def agree(local_exc, device="cpu"):
+    """Status exchange BEFORE a result collective (mirrors gpcore_dist.hip dist_agree): every rank contributes one word --
+    0, or the gpcore status / 1 of the exception its local part raised -- so a rank that failed locally never leaves its peers
+    blocked in the result all_gather.  The failing rank re-raises its own exception, the others raise PeerFailure."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        if local_exc is not None:
+            raise local_exc
+        return
+    code = 0 if local_exc is None else int(getattr(local_exc, "status", 1) or 1)
+    mine = torch.tensor([float(code)], dtype=torch.float64, device=device)
+    parts = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, mine)
+    st, bad = status_scan([float(p.item()) for p in parts], dist.get_rank())
+    if st == 0:
+        return
+    if local_exc is not None:
+        raise local_exc
+    raise PeerFailure(bad, int(parts[bad].item()))
+
+
 def all_gather_rows(local, total_rows, device="cpu"):
     """Assemble per-rank result rows (each rank holds the rows of shard_range(total_rows, rank, world)) on every rank.
     Message size is tiny (B x (1+P) doubles), one collective."""
@@ -78,11 +120,14 @@ def lml_grad_sharded(evaluate, thetas, device="cpu"):
     thetas = np.ascontiguousarray(np.atleast_2d(thetas), dtype=np.float64)
     B = thetas.shape[0]
     lo, hi = shard_range(B, rank, world)
+    local, failed = np.zeros((0, 1 + thetas.shape[1])), None
     if hi > lo:
-        lml, grad = evaluate(thetas[lo:hi])
-        local = np.concatenate([np.asarray(lml).reshape(-1, 1), np.atleast_2d(grad)], axis=1)
-    else:
-        local = np.zeros((0, 1 + thetas.shape[1]))
+        try:
+            lml, grad = evaluate(thetas[lo:hi])
+            local = np.concatenate([np.asarray(lml).reshape(-1, 1), np.atleast_2d(grad)], axis=1)
+        except Exception as e:        # noqa: BLE001 -- whatever failed here, the peers must hear of it before they gather
+            failed = e
+    agree(failed, device=device)
     full = all_gather_rows(local, B, device=device)
     return full[:, 0].copy(), full[:, 1:].copy()
 
@@ -96,10 +141,13 @@ def predict_sharded(predict, Xs, device="cpu"):
     Xs = np.asarray(Xs)
     m = Xs.shape[0]
     lo, hi = shard_range(m, rank, world)
+    local, failed = np.zeros((0, 2)), None
     if hi > lo:
-        mean, var = predict(Xs[lo:hi])
-        local = np.stack([np.asarray(mean, dtype=np.float64), np.asarray(var, dtype=np.float64)], axis=1)
-    else:
-        local = np.zeros((0, 2))
+        try:
+            mean, var = predict(Xs[lo:hi])
+            local = np.stack([np.asarray(mean, dtype=np.float64), np.asarray(var, dtype=np.float64)], axis=1)
+        except Exception as e:        # noqa: BLE001
+            failed = e
+    agree(failed, device=device)
     full = all_gather_rows(local, m, device=device)
     return full[:, 0].copy(), full[:, 1].copy()

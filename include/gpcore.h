@@ -36,7 +36,8 @@ typedef enum gp_status {
     GP_ENOMEM = 3, /* host or device allocation failed                                            */
     GP_EHIP = 4,   /* HIP runtime error (message in gp_last_error)                                */
     GP_ERANGE = 5, /* 1-based hyper-parameter position out of range (Scala: MatchError)           */
-    GP_ERCCL = 6   /* RCCL missing or a collective failed (message in gp_last_error)               */
+    GP_ERCCL = 6,  /* RCCL missing or a collective failed (message in gp_last_error)               */
+    GP_EPEER = 7   /* gp_dist_*: another rank of the group failed; nothing was exchanged, this rank is intact */
 } gp_status;
 
 typedef struct gp_ctx gp_ctx;     /* device + stream + workspaces                                  */
@@ -264,14 +265,25 @@ gp_status gp_small_maximize_ucb(gp_small *small, int g, const double *starts, in
  * GpPredictor.obtainOptimalHyperParams (gp/regression/GpPredictor.scala:126-142) / MeshHyperParamsLogLikelihoodEvaluator
  * (gp/classification/MeshHyperParamsLogLikelihoodEvaluator.scala:26-40) visit one by one, and the rows of testData in
  * GpPredictor.predict (:24-43).  Units are sharded contiguously, unit u -> rank u / ceil(U / world); every rank passes the SAME
- * arguments and receives the complete result; the only collective is ONE all-gather of the per-rank results per call.  The
- * Cholesky itself stays single-GPU.  RCCL is loaded at run time; without it these return GP_ERCCL.
+ * arguments and receives the complete result; the only collective is ONE all-gather of the per-rank results per call, preceded
+ * by an all-gather of one status word per rank: a rank whose local part fails (GP_ENOMEM, GP_EHIP, ...) still takes part in
+ * the status exchange, then EVERY rank returns without entering the result collective -- the failing rank with its own status,
+ * its peers with GP_EPEER -- so one rank's failure never leaves the group blocked.  Argument checks that every rank sees
+ * alike (GP_EINVAL) return before any collective.  The Cholesky itself stays single-GPU.  RCCL is loaded at run time;
+ * without it these return GP_ERCCL.
  * Rendezvous: rank 0 obtains an id and hands its GP_DIST_ID_BYTES bytes to the other ranks over whatever channel the host
  * program has (a file, a socket, torch.distributed); then every rank calls gp_dist_init on the context of ITS device. */
 #define GP_DIST_ID_BYTES 128
 gp_status gp_dist_unique_id(gp_ctx *ctx, unsigned char *id /* [GP_DIST_ID_BYTES] */);
 gp_status gp_dist_init(gp_ctx *ctx, const unsigned char *id, int rank, int world, gp_dist **out);
 void gp_dist_destroy(gp_dist *dist);
+/* The agreement rule of the status exchange, host only (no device, no communicator): status[world] = every rank's gp_status as
+ * a double.  All zero -> GP_OK; status[rank] != 0 -> that status; otherwise GP_EPEER.  *bad_rank (may be NULL) = the first failing
+ * rank (this rank if it failed itself), -1 if none.  Exported so that a host with its own transport (MPI, sockets) can apply the same rule. */
+gp_status gp_dist_status_scan(const double *status, int world, int rank, int *bad_rank);
+/* Test hook: the NEXT gp_dist_lml_grad_batched / gp_dist_predict on this communicator fails locally with GP_ENOMEM after
+ * its evaluation (exercises the status exchange; tests/test_gpu_dist.py). */
+gp_status gp_dist_inject_failure(gp_dist *dist);
 /* [lo, hi) of `total` units owned by this rank */
 gp_status gp_dist_shard(const gp_dist *dist, int total, int *lo, int *hi);
 /* gp_lml_grad_rbf_batched over B settings sharded B/world per GPU (BASELINE config C3); lml[B], grad[B x nparams], info[B]

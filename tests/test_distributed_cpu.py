@@ -94,3 +94,74 @@ def test_lml_grad_sharded_two_ranks_gloo():
         np.testing.assert_array_equal(grad, np.stack([r[1] for r in ref]))
         np.testing.assert_array_equal(pmean, rmean)          # assembled in test-point order on every rank
         np.testing.assert_array_equal(pvar, rvar)
+
+
+def _failing_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    from gp_algos_amd import dist
+    from gp_algos_amd._lib import GpCoreError
+    dist.init("gloo")
+    thetas = np.arange(15.0).reshape(5, 3)
+
+    def evaluate(th):
+        if rank == 1:
+            raise GpCoreError(3, "injected: hipMalloc failed on this rank")       # GP_ENOMEM on ONE rank only
+        return th[:, 0], th
+
+    got = None
+    try:
+        dist.lml_grad_sharded(evaluate, thetas)
+    except dist.PeerFailure as e:
+        got = ("peer", e.bad_rank, e.status)
+    except GpCoreError as e:
+        got = ("own", rank, e.status)
+    # the group is still usable afterwards: nobody is stuck inside a collective, nothing is half-exchanged
+    lml, grad = dist.lml_grad_sharded(lambda th: (th[:, 0], th), thetas)
+    dist.barrier()
+    out.put((rank, got, lml.tolist()))
+    import torch.distributed as td
+    td.destroy_process_group()
+
+
+def test_failing_rank_does_not_strand_its_peer_gloo():
+    """a rank whose local evaluation fails must not leave the others blocked inside the all_gather.
+    dist.agree exchanges one status word per rank first (the torch.distributed form of gpcore_dist.hip dist_agree)."""
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_failing_worker, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    assert res[0][1] == ("peer", 1, 3)        # rank 0 was fine and is told who failed and how
+    assert res[1][1] == ("own", 1, 3)         # rank 1 sees its own error
+    assert res[0][2] == res[1][2] == [0.0, 3.0, 6.0, 9.0, 12.0]
+
+
+def test_status_scan_rule_c_abi_and_python_agree():
+    """gp_dist_status_scan (host only: no device, no communicator) and dist.status_scan implement the same agreement rule."""
+    import ctypes as C
+    import __graft_entry__ as entry
+    from gp_algos_amd import _lib, dist
+    entry.build()
+    lib = _lib.load()
+    cases = [([0, 0, 0, 0], 2, (0, -1)), ([0, 3, 0, 4], 0, (_lib.GP_EPEER, 1)), ([0, 3, 0, 4], 1, (3, 1)),
+             ([0, 3, 0, 4], 3, (4, 3)), ([2], 0, (2, 0)), ([0], 0, (0, -1))]
+    for status, rank, want in cases:
+        arr = (C.c_double * len(status))(*[float(s) for s in status])
+        bad = C.c_int(-7)
+        st = lib.gp_dist_status_scan(arr, len(status), rank, C.byref(bad))
+        assert (st, bad.value) == want, (status, rank)
+        assert dist.status_scan(status, rank) == want
+    assert lib.gp_dist_status_scan(None, 2, 0, None) == _lib.GP_EINVAL
+    arr = (C.c_double * 2)(0.0, 0.0)
+    assert lib.gp_dist_status_scan(arr, 2, 2, None) == _lib.GP_EINVAL
+    assert lib.gp_dist_status_scan(arr, 2, 1, None) == _lib.GP_OK      # bad_rank may be NULL

@@ -54,3 +54,30 @@ def test_dist_non_pd_setting_and_argument_errors(ctx):
     assert ctx._lib.gp_dist_init(ctx.h, ident, 2, 2, C.byref(h)) == L.GP_EINVAL      # rank outside [0, world)
     assert ctx._lib.gp_dist_init(ctx.h, None, 0, 1, C.byref(h)) == L.GP_EINVAL
     grp.close()
+
+
+def test_dist_local_failure_goes_through_the_status_exchange(ctx):
+    """gpcore_dist.hip dist_agree: a rank that fails locally still takes part in the status all-gather, returns its own status
+    (here the injected GP_ENOMEM) without entering the result collective, and the communicator stays usable."""
+    from gp_algos_amd import _lib as L
+    from gp_algos_amd.core import DistGroup, RegressionModel
+    p = synth.regression(120, 2, 30, 5, 6, 7, synth.ard_theta(2, 1.0, 1.0, 0.1))
+    thetas = p["theta"][None, :] * np.linspace(0.8, 1.4, 3)[:, None]
+    grp = DistGroup(ctx, 0, 1)
+    grp.inject_failure()
+    with pytest.raises(L.GpCoreError) as ei:
+        grp.lml_grad_batched(p["X"], p["y"], thetas)
+    assert ei.value.status == L.GP_ENOMEM
+    lml, grad, info = grp.lml_grad_batched(p["X"], p["y"], thetas)          # next call: fine, bit-equal to the single-GPU path
+    l0, g0, _ = ctx.lml_grad_batched(p["X"], p["y"], thetas)
+    assert np.array_equal(lml, l0) and np.array_equal(grad, g0)
+    mdl = RegressionModel(ctx, p["X"], p["y"], p["theta"])
+    grp.inject_failure()
+    with pytest.raises(L.GpCoreError) as ei:
+        grp.predict(mdl, p["Xs"])
+    assert ei.value.status == L.GP_ENOMEM
+    mean, var = grp.predict(mdl, p["Xs"])
+    m0, v0, _ = mdl.predict(p["Xs"])
+    assert np.array_equal(mean, m0) and np.array_equal(var, v0)
+    mdl.close()
+    grp.close()
