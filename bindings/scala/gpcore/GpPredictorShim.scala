@@ -2,19 +2,33 @@ package gp.regression
 
 import breeze.linalg.{DenseMatrix, DenseVector}
 import gpcore.Native
+import gp.regression.Co2Prediction.Co2Kernel
+import optimization.Optimization
+import optimization.Optimization.BreezeLbfgsOptimizer
 import utils.KernelRequisites.{GaussianRbfKernel, KernelFunc, KernelFuncHyperParams}
 import utils.MatrixUtils
 import utils.StatsUtils.GaussianDistribution
 
 /** Drop-in body for gp.regression.GpPredictor (gp/regression/GpPredictor.scala:15-150): same constructor and method
-  * signatures, numerics in libgpcore.so.  A GaussianRbfKernel goes to the fused device path; any other KernelFunc keeps the
-  * reference's Scala loops for the Gram matrices (MatrixUtils.buildKernelMatrix) and hands them to gp_fit_from_gram /
-  * gp_predict_from_gram / gp_posterior_from_gram, so the O(n^3) and O(n^2 m) work still runs on the GPU. */
+  * signatures, numerics in libgpcore.so.  Kernel dispatch (SURVEY.md 8b), the same in EVERY method:
+  *   GaussianRbfKernel          -> the fused device path (gp_*_rbf);
+  *   Co2Prediction.Co2Kernel    -> its own device path (gp_*_co2: Gram, derivatives, fit, LML gradient, L-BFGS);
+  *   any other KernelFunc       -> the reference's Scala loops build the matrices (MatrixUtils.buildKernelMatrix /
+  *                                 buildMatrixWithFunc) and hand them to gp_fit_from_gram / gp_predict_from_gram /
+  *                                 gp_posterior_from_gram / gp_lml_grad_from_gram, so the O(n^3), O(n^2 m) and O(P n^2) work
+  *                                 still runs on the GPU; its hyper-parameter fit is the reference's own host L-BFGS
+  *                                 (BreezeLbfgsOptimizer) over that objective. */
 class GpPredictor(val kernelFunc: KernelFunc) {
   import GpPredictor._
   import Native.{defaultCtx => ctx, dense, rethrowNotPd}
 
   private def isRbf(k: KernelFunc) = k.isInstanceOf[GaussianRbfKernel]
+  private def isCo2(k: KernelFunc) = k.isInstanceOf[Co2Kernel]
+  /** the n inputs of a 1-D training / test matrix as the contiguous array the gp_*_co2 entry points take */
+  private def column(x: DenseMatrix[Double]): Array[Double] = {
+    require(x.cols == 1, "This kernel is applicable only for 1D objects")      // Co2Prediction.scala:40
+    x(::, 0).toArray
+  }
 
   private def withModel[T](x: DenseMatrix[Double], hp: KernelFuncHyperParams, sigmaNoise: Option[Double],
                            targets: DenseVector[Double])(body: (Long, KernelFunc) => T): T = {
@@ -25,6 +39,8 @@ class GpPredictor(val kernelFunc: KernelFunc) {
         val xc = dense(x)   // views cross the API (GpPredictorTest.scala:66): offset and majorStride are passed through
         Native.fitRbf(ctx, xc.data, xc.offset, xc.rows, xc.cols, xc.majorStride, targets.toArray, hp.toDenseVector.toArray,
           sigmaNoise.getOrElse(Double.NaN))
+      } else if (isCo2(kf)) {
+        Native.fitCo2(ctx, column(x), x.rows, targets.toArray, hp.toDenseVector.toArray, sigmaNoise.getOrElse(Double.NaN))
       } else {
         val k = MatrixUtils.buildKernelMatrix(kf, x)
         sigmaNoise.foreach(v => (0 until k.rows).foreach(i => k(i, i) += v))      // un-squared, GpPredictor.scala:116
@@ -51,7 +67,7 @@ class GpPredictor(val kernelFunc: KernelFunc) {
     withModel(input.trainingData, hyperParams, input.sigmaNoise, input.targets) { (model, kf) =>
       val m = input.testData.rows; val n = input.trainingData.rows
       val mean = new Array[Double](m); val cov = new Array[Double](m * m); val lml = new Array[Double](1)
-      if (isRbf(kf)) {
+      if (isRbf(kf) || isCo2(kf)) {      // the model rebuilds K* and K** with its own kernel on the device
         val xs = dense(input.testData)
         Native.predict(ctx, model, xs.data, xs.offset, m, xs.cols, xs.majorStride, mean, null, cov)
       } else {
@@ -96,11 +112,27 @@ class GpPredictor(val kernelFunc: KernelFunc) {
 
   def logLikelihoodWithDerivatives(input: PredictionTrainingInput, hyperParams: KernelFuncHyperParams,
                                    optimizedParamsNum: Int): (Double, DenseVector[Double]) = {
-    require(isRbf(kernelFunc), "device LML gradient is implemented for GaussianRbfKernel")
-    val x = dense(input.trainingData)
+    val kf = kernelFunc.changeHyperParams(hyperParams.toDenseVector)
+    val theta = hyperParams.toDenseVector.toArray
+    val sn = input.sigmaNoise.getOrElse(Double.NaN)
     val lml = new Array[Double](1); val grad = new Array[Double](optimizedParamsNum); val info = new Array[Int](1)
-    Native.lmlGradBatched(ctx, x.data, x.offset, x.rows, x.cols, x.majorStride, input.targets.toArray,
-      hyperParams.toDenseVector.toArray, 1, optimizedParamsNum, input.sigmaNoise.getOrElse(Double.NaN), lml, grad, info)
+    kf match {
+      case _: GaussianRbfKernel =>
+        val x = dense(input.trainingData)
+        Native.lmlGradBatched(ctx, x.data, x.offset, x.rows, x.cols, x.majorStride, input.targets.toArray, theta, 1,
+          optimizedParamsNum, sn, lml, grad, info)
+      case _: Co2Kernel =>
+        Native.lmlGradCo2Batched(ctx, column(input.trainingData), input.trainingData.rows, input.targets.toArray, theta, 1,
+          optimizedParamsNum, sn, lml, grad, info)
+      case other =>
+        // GpPredictor.scala:62,74 on the host (the kernel is opaque Scala code), :63-78 on the device
+        val k = MatrixUtils.buildKernelMatrix(other, input.trainingData)
+        val dks = (1 to optimizedParamsNum).map { i =>
+          MatrixUtils.buildMatrixWithFunc(input.trainingData)(other.derAfterHyperParam(i)).data }.toArray
+        rethrowNotPd {
+          lml(0) = Native.lmlGradFromGram(ctx, k.data, k.offset, k.rows, k.majorStride, input.targets.toArray, dks, k.rows, sn, grad)
+        }
+    }
     if (info(0) != 0)   // breeze.linalg.cholesky throws inside preComputeComponents (GpPredictor.scala:63-64,120)
       throw new breeze.linalg.NotConvergedException(breeze.linalg.NotConvergedException.Iterations,
         "matrix not positive definite at pivot " + info(0))
@@ -110,13 +142,28 @@ class GpPredictor(val kernelFunc: KernelFunc) {
   // GpPredictor.scala:126-142 -- BreezeLbfgsOptimizer(maxIter = 20), m = 4, best-seen point; optimizeNoise = false keeps sn fixed
   def obtainOptimalHyperParams(trainingData: DenseMatrix[Double], sigmaNoise: Option[Double], targets: DenseVector[Double],
                                optimizeNoise: Boolean): KernelFuncHyperParams = {
-    val x = dense(trainingData)
     val theta = kernelFunc.hyperParams.toDenseVector.toArray
-    rethrowNotPd {
-      Native.optimizeRbf(ctx, x.data, x.offset, x.rows, x.cols, x.majorStride, targets.toArray, theta,
-        if (optimizeNoise) theta.length else theta.length - 1, sigmaNoise.getOrElse(Double.NaN), 20, 4)
+    val nparams = if (optimizeNoise) theta.length else theta.length - 1
+    val sn = sigmaNoise.getOrElse(Double.NaN)
+    kernelFunc match {
+      case _: GaussianRbfKernel =>     // device-resident L-BFGS, trial steps of a line search as one lockstep batch
+        val x = dense(trainingData)
+        rethrowNotPd { Native.optimizeRbf(ctx, x.data, x.offset, x.rows, x.cols, x.majorStride, targets.toArray, theta, nparams, sn, 20, 4) }
+        kernelFunc.hyperParams.fromDenseVector(DenseVector(theta))
+      case _: Co2Kernel =>             // MasterThesisRelatedTasks.scala:59-71 -> predictWithParamsOptimization on co2GpPredictor
+        rethrowNotPd { Native.optimizeCo2(ctx, column(trainingData), trainingData.rows, targets.toArray, theta, nparams, sn, 20, 4) }
+        kernelFunc.hyperParams.fromDenseVector(DenseVector(theta))
+      case _ =>                        // the reference's own loop (:128-141): host L-BFGS over the (device-evaluated) objective
+        val breezeOptimizer = new BreezeLbfgsOptimizer(maxIter = 20)
+        val initPoint = if (optimizeNoise) theta else theta.take(theta.length - 1)
+        val llObjFunction: Optimization.objectiveFunctionWithGradient = { currentParams =>
+          val hyperParams = kernelFunc.hyperParams.fromDenseVector(DenseVector(currentParams))
+          val ptInput = PredictionTrainingInput(trainingData = trainingData, targets = targets, sigmaNoise = sigmaNoise)
+          val (value, gradient) = logLikelihoodWithDerivatives(ptInput, hyperParams, currentParams.length)
+          (value, gradient.toArray)
+        }
+        kernelFunc.hyperParams.fromDenseVector(DenseVector(breezeOptimizer.maximize(llObjFunction, initPoint)))
     }
-    kernelFunc.hyperParams.fromDenseVector(DenseVector(theta))
   }
 
   def predictWithParamsOptimization(input: PredictionInput, optimizeNoise: Boolean): (GaussianDistribution, Double, KernelFuncHyperParams) = {

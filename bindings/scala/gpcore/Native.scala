@@ -23,8 +23,10 @@ object Native {
   @native def posteriorFromGram(ctx: Long, ks: Array[Double], m: Int, n: Int, kss: Array[Double], l: Array[Double], loff: Int, ldl: Int, alpha: Array[Double], mean: Array[Double], cov: Array[Double], v: Array[Double]): Unit
   @native def predictFromGram(ctx: Long, model: Long, ks: Array[Double], m: Int, n: Int, kss: Array[Double], mean: Array[Double], cov: Array[Double]): Unit
   @native def lmlGradBatched(ctx: Long, x: Array[Double], xoff: Int, n: Int, d: Int, ldx: Int, y: Array[Double], thetas: Array[Double], b: Int, nparams: Int, sigmaNoiseOrNaN: Double, lml: Array[Double], grad: Array[Double], info: Array[Int]): Unit
+  @native def lmlGradFromGram(ctx: Long, k: Array[Double], koff: Int, n: Int, ldk: Int, y: Array[Double], dks: Array[Array[Double]], lddk: Int, sigmaNoiseOrNaN: Double, grad: Array[Double]): Double
   @native def optimizeRbf(ctx: Long, x: Array[Double], xoff: Int, n: Int, d: Int, ldx: Int, y: Array[Double], thetaInOut: Array[Double], nparams: Int, sigmaNoiseOrNaN: Double, maxIter: Int, history: Int): Double
   @native def epLmlRbfBatched(ctx: Long, x: Array[Double], xoff: Int, n: Int, d: Int, ldx: Int, y: Array[Int], thetas: Array[Double], b: Int, stopEps: Double, maxSweeps: Int, strict: Boolean, lml: Array[Double], sweeps: Array[Int], info: Array[Int]): Unit
+  @native def epLmlGradRbfBatched(ctx: Long, x: Array[Double], xoff: Int, n: Int, d: Int, ldx: Int, y: Array[Int], thetas: Array[Double], b: Int, stopEps: Double, maxSweeps: Int, strict: Boolean, lml: Array[Double], grad: Array[Double], sweeps: Array[Int], info: Array[Int]): Unit
   @native def potrfLower(ctx: Long, a: Array[Double], off: Int, n: Int, lda: Int): Unit
   @native def trsmLower(ctx: Long, trans: Int, l: Array[Double], loff: Int, n: Int, ldl: Int, b: Array[Double], boff: Int, nrhs: Int, ldb: Int): Unit
   @native def invLower(ctx: Long, l: Array[Double], loff: Int, n: Int, ldl: Int, out: Array[Double]): Unit
@@ -39,12 +41,19 @@ object Native {
   @native def epOptimizeRbf(ctx: Long, x: Array[Double], xoff: Int, n: Int, d: Int, ldx: Int, y: Array[Int], thetaInOut: Array[Double], stopEps: Double, maxSweeps: Int, strict: Boolean, maxIter: Int, history: Int): Double
   // batched small-n posteriors: GPOptimizer (GP-UCB), GPUnscentedKalmanFilter (GP-UKF)
   @native def smallFit(ctx: Long, x: Array[Double], xoff: Int, n: Int, d: Int, ldx: Int, y: Array[Double], g: Int, thetas: Array[Double], sigmaNoiseOrNaN: Double, capacity: Int): Long
+  /** G models from factors the caller holds -- the (L, alpha) of preComputeComponents that GPUnscentedKalmanFilter.scala:116-132 keeps per state dimension; ls / alphas: g blocks of n x n (ld n) / n */
+  @native def smallFromFactors(ctx: Long, x: Array[Double], xoff: Int, n: Int, d: Int, ldx: Int, thetas: Array[Double], g: Int, ls: Array[Double], alphas: Array[Double], capacity: Int): Long
+  @native def smallSize(small: Long): Array[Int]      // (n, capacity, g)
+  @native def smallGet(ctx: Long, small: Long, what: Int, g: Int, out: Array[Double], ld: Int): Unit
   @native def smallDestroy(small: Long): Unit
   @native def smallPosterior(ctx: Long, small: Long, g: Int, xs: Array[Double], xsoff: Int, m: Int, d: Int, ldxs: Int, mean: Array[Double], variance: Array[Double]): Unit
   @native def smallUcb(ctx: Long, small: Long, g: Int, xs: Array[Double], xsoff: Int, m: Int, d: Int, ldxs: Int, kappa: Double, value: Array[Double], grad: Array[Double]): Unit
   @native def smallAppend(ctx: Long, small: Long, d: Int, g: Int, xNew: Array[Double], yNew: Array[Double]): Unit
   @native def smallMaximizeUcb(ctx: Long, small: Long, g: Int, starts: Array[Double], c: Int, d: Int, kappa: Double, maxIter: Int, history: Int, bestX: Array[Double]): Double
   // Co2Kernel
+  @native def gramCo2(ctx: Long, x: Array[Double], n: Int, theta: Array[Double], out: Array[Double]): Unit
+  @native def dgramCo2(ctx: Long, x: Array[Double], n: Int, theta: Array[Double], pos: Int, out: Array[Double]): Unit
+  @native def crossGramCo2(ctx: Long, xs: Array[Double], m: Int, x: Array[Double], n: Int, theta: Array[Double], out: Array[Double]): Unit
   @native def fitCo2(ctx: Long, x: Array[Double], n: Int, y: Array[Double], theta: Array[Double], sigmaNoiseOrNaN: Double): Long
   @native def lmlGradCo2Batched(ctx: Long, x: Array[Double], n: Int, y: Array[Double], thetas: Array[Double], b: Int, nparams: Int, sigmaNoiseOrNaN: Double, lml: Array[Double], grad: Array[Double], info: Array[Int]): Unit
   @native def optimizeCo2(ctx: Long, x: Array[Double], n: Int, y: Array[Double], thetaInOut: Array[Double], nparams: Int, sigmaNoiseOrNaN: Double, maxIter: Int, history: Int): Double

@@ -60,6 +60,7 @@ SIGNATURES = {
     "gp_posterior_from_gram": (_i, [_vp, _dp, _i, _i, _i, _dp, _i, _dp, _dp, _i, _dp, _dp, _dp, _dp, _i, _dp, _i]),
     "gp_predict_from_gram": (_i, [_vp, _dp, _i, _i, _dp, _i, _dp, _dp, _dp, _dp, _i]),
     "gp_lml_grad_rbf_batched": (_i, [_vp, _dp, _i, _i, _i, _dp, _dp, _i, _i, _d, _dp, _dp, _ip]),
+    "gp_lml_grad_from_gram": (_i, [_vp, _dp, _i, _i, _dp, C.POINTER(_dp), _i, _i, _d, _dp, _dp, _ip]),
     "gp_optimize_rbf": (_i, [_vp, _dp, _i, _i, _i, _dp, _dp, _i, _d, _i, _i, _dp, _dp, _ip, _ip]),
     "gp_ep_create": (_i, [_vp, _dp, _i, _i, C.POINTER(C.c_int32), C.POINTER(_vp)]),
     "gp_ep_sweep": (_i, [_vp, _i, _dp, _dp, _ip]),

@@ -179,6 +179,23 @@ class Context:
                                                      info.ctypes.data_as(C.POINTER(C.c_int))))
         return lml, grad[:, :nparams], info
 
+    def lml_grad_from_gram(self, K, y, dKs, sigma_noise=None):
+        """gp_lml_grad_from_gram: (lml, grad[len(dKs)]) for ANY kernel from host-built K and derivative matrices dKs (symmetric)."""
+        K, y = L.f64(K), L.f64(y)
+        n = K.shape[0]
+        if K.shape != (n, n) or y.size != n:
+            raise ValueError("dimension mismatch")
+        dKs = [L.f64(D) for D in dKs]
+        if any(D.shape != (n, n) for D in dKs):
+            raise ValueError("every derivative matrix must be n x n")
+        P = len(dKs)
+        ptrs = (C.POINTER(C.c_double) * max(P, 1))(*[L.dptr(D) for D in dKs])
+        lml, grad, info = C.c_double(), np.zeros(max(P, 1)), C.c_int()
+        sn = float("nan") if sigma_noise is None else float(sigma_noise)
+        self.check(self._lib.gp_lml_grad_from_gram(self.h, L.dptr(K), n, n, L.dptr(y), ptrs, P, n, sn, C.byref(lml), L.dptr(grad), C.byref(info)),
+                   info.value)
+        return lml.value, grad[:P].copy()
+
     def optimize_co2(self, x, y, theta0, nparams=11, sigma_noise=None, max_iter=20, history=4):
         x, y = L.f64(np.asarray(x, dtype=np.float64).reshape(-1)), L.f64(y)
         theta0 = np.ascontiguousarray(theta0, dtype=np.float64)

@@ -896,6 +896,54 @@ gp_status gp_fit_from_gram(gp_ctx *ctx, const double *K, int n, int ldk, const d
     return GP_OK;
 }
 
+// GpPredictor.logLikelihoodWithDerivatives (gp/regression/GpPredictor.scala:60-80) for ANY KernelFunc: the host evaluates the kernel
+// matrix and the P derivative matrices with the reference's own loops (buildKernelMatrix / buildMatrixWithFunc(trainingData)(
+// derAfterHyperParam(i)), :62,74), the device does everything that is O(n^3) or O(P n^2): factorisation, alpha, K^-1 = L^-T L^-1
+// (:66-67) and g_p = 1/2 tr((alpha alpha^T - K^-1) dK_p) (:76).  sigma_noise (NaN = None) is added un-squared to K's diagonal (:116).
+gp_status gp_lml_grad_from_gram(gp_ctx *ctx, const double *K, int n, int ldk, const double *y, const double *const *dK, int nparams, int lddk,
+                                double sigma_noise, double *lml, double *grad, int *info) {
+    if (!ctx) return GP_EINVAL;
+    if (info) *info = 0;
+    GP_REQUIRE(ctx, K && y && lml && n >= 1 && ldk >= n && nparams >= 0 && (nparams == 0 || (dK && grad && lddk >= n)), "bad arguments");
+    for (int p = 0; p < nparams; ++p) GP_REQUIRE(ctx, dK[p], "a derivative matrix pointer is NULL");
+    GP_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    gp_model *m = nullptr;
+    GP_TRY(model_alloc(ctx, n, 0, false, &m));
+    const int np = m->np;
+    int h = 0;
+    gp_status st = upload_2d(ctx, m->dL, m->ldl, K, ldk, n, n);
+    if (st == GP_OK) st = upload_2d(ctx, m->dy, n, y, n, n, 1);
+    if (st == GP_OK) {
+        if (!std::isnan(sigma_noise)) gpk_add_diag(s, m->dL, n, m->ldl, sigma_noise);
+        model_factor(m);
+        st = gp_model_status(m, &h);
+    }
+    if (info) *info = h;
+    if (st == GP_OK) st = download_2d(ctx, lml, 1, m->dlml, 1, 1, 1);
+    if (st == GP_OK && nparams > 0) {
+        double *T = nullptr, *Kinv = nullptr, *D = nullptr, *small = nullptr;
+        st = ws_get(ctx, WS_VT, sizeof(double) * (size_t)np * np, &T);
+        if (st == GP_OK) st = ws_get(ctx, WS_D, sizeof(double) * (size_t)np * np, &Kinv);
+        if (st == GP_OK) st = ws_get(ctx, WS_B, sizeof(double) * (size_t)np * np, &D);
+        if (st == GP_OK) st = ws_get(ctx, WS_C, sizeof(double) * ((size_t)2 * np + nparams), &small);   // alpha | partial | g[nparams]
+        double *alpha = small, *partial = small + np, *g = partial + np;
+        if (st == GP_OK) st = gpi_model_alpha(m, alpha);
+        if (st == GP_OK) {
+            inverse_transpose_lower(ctx, T, m->dL, np, m->ldl, m->ddinv);                           // T = L^-T
+            gpk_gemm_nt(s, np, np, np, 1.0, T, np, T, np, 0.0, Kinv, np, 1, 1);                      // K^-1 = T T^T (lower)
+        }
+        for (int p = 0; p < nparams && st == GP_OK; ++p) {
+            st = upload_2d(ctx, D, np, dK[p], lddk, n, n);        // stream-ordered: the trace of p - 1 has read D before this lands
+            if (st == GP_OK) gpk_co2_trace(s, n, alpha, Kinv, np, D, np, partial, g + p);
+        }
+        if (st == GP_OK) st = download_2d(ctx, grad, nparams, g, nparams, nparams, 1);
+    }
+    if (st == GP_OK) { hipError_t e = hipGetLastError(); if (e != hipSuccess) { GP_SET_ERR(ctx, "launch failed: %s", hipGetErrorString(e)); st = GP_EHIP; } }
+    gp_model_destroy(m);
+    return st;
+}
+
 gp_status gp_model_get(gp_model *m, int what, double *out, int ld) {
     if (!m || !out) return GP_EINVAL;
     gp_ctx *ctx = m->ctx;

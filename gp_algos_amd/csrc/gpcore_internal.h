@@ -111,6 +111,8 @@ void gpk_gram_cross(hipStream_t s, const double *Xs, int m, int ldxs, const doub
 // Co2Kernel (gp/regression/Co2Prediction.scala:29-137), 1-D inputs, theta = hp1..hp11 on the host; pos = 0: kernel, 1..11: derivative
 void gpk_co2_gram(hipStream_t s, const double *xr, int nr, const double *xc, int nc, const double *theta, int pos, double *K, int ldk, int sym,
                   int full, double extra);
+// out[0] = 1/2 tr((alpha alpha^T - Kinv) D) for ANY symmetric D given as a matrix (lower triangles read; partial: n doubles of scratch):
+// the per-parameter term of GpPredictor.logLikelihoodWithDerivatives (:76) when the derivative matrix is materialised
 void gpk_co2_trace(hipStream_t s, int n, const double *alpha, const double *Kinv, int ldk, const double *D, int ldd, double *partial, double *out);
 double gpk_co2_kss(const double *theta);
 // set rows/cols [n, np) of the np x np matrix to identity (pad block) and zero the cross blocks.
@@ -124,6 +126,7 @@ void gpk_transpose(hipStream_t s, double *dst, int ldd, const double *src, int l
 // stage = 0: dst (lower form) <- (upper form src)^T, block-lower part and diagonal blocks only.
 void gpk_lw_transpose(hipStream_t s, double *dst, int ldd, const double *src, int lds, int np, int stage);
 void gpk_set_identity(hipStream_t s, double *A, int n, int lda);
+void gpk_add_diag(hipStream_t s, double *A, int n, int lda, double v);   // A(i,i) += v, i < n
 // LML-gradient traces (GpPredictor.scala:70-78 fused): out[0..d+1] = g_p for W = alpha alpha^T - Kinv (lower triangle of Kinv read)
 void gpk_lml_grad_traces(hipStream_t s, const double *X, int n, int d, int ldx, const double *theta, const double *alpha,
                          const double *Kinv, int ldk, double *partials, double *out);

@@ -148,6 +148,10 @@ __global__ __launch_bounds__(256) void lw_transpose_kernel(double *__restrict__ 
     }
 }
 
+__global__ void add_diag_kernel(double *A, int n, int lda, double v) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) A[i + (size_t)i * lda] += v;
+}
 __global__ void set_identity_kernel(double *A, int n, int lda) {
     size_t total = (size_t)n * n;
     for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
@@ -310,6 +314,9 @@ void gpk_transpose(hipStream_t s, double *dst, int ldd, const double *src, int l
 }
 void gpk_lw_transpose(hipStream_t s, double *dst, int ldd, const double *src, int lds, int np, int stage) {
     hipLaunchKernelGGL(lw_transpose_kernel, dim3(np / 64, np / 64), dim3(256), 0, s, dst, ldd, src, lds, stage);
+}
+void gpk_add_diag(hipStream_t s, double *A, int n, int lda, double v) {
+    if (n > 0) hipLaunchKernelGGL(add_diag_kernel, dim3((n + 255) / 256), dim3(256), 0, s, A, n, lda, v);
 }
 void gpk_set_identity(hipStream_t s, double *A, int n, int lda) {
     hipLaunchKernelGGL(set_identity_kernel, dim3(1024), dim3(256), 0, s, A, n, lda);

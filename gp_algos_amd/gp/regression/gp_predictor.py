@@ -126,7 +126,11 @@ class GpPredictor:
             lml, grad, info = default_context().lml_grad_batched(X, input.targets, kf.rbfParams.toDenseVector()[None, :],
                                                                  nparams=optimizedParamsNum, sigma_noise=input.sigmaNoise)
         else:
-            raise NotImplementedError("device LML gradient is implemented for GaussianRbfKernel and Co2Kernel")
+            # any other KernelFunc: K and the derivative matrices by the reference's host loops (:62, :74), the
+            # factorisation, K^-1 and the traces on the device (gp_lml_grad_from_gram)
+            K = matrix_utils.buildKernelMatrix(kf, X)
+            dKs = [matrix_utils.buildMatrixWithFunc(X)(kf.derAfterHyperParam(i)) for i in range(1, optimizedParamsNum + 1)]
+            return default_context().lml_grad_from_gram(K, input.targets, dKs, sigma_noise=input.sigmaNoise)
         if info[0]:
             from ..._lib import NotPositiveDefinite
             raise NotPositiveDefinite(2, "matrix not positive definite at pivot %d" % info[0], int(info[0]))

@@ -161,6 +161,15 @@ gp_status gp_predict_from_gram(gp_model *model, const double *Ks, int m, int ldk
  * lml[B], grad[B x nparams] row-major.  info[B]: 0 or failing pivot per setting (lml = NaN there). */
 gp_status gp_lml_grad_rbf_batched(gp_ctx *ctx, const double *X, int n, int d, int ldx, const double *y, const double *thetas, int B, int nparams, double sigma_noise, double *lml, double *grad, int *info);
 
+/* The same method (GpPredictor.scala:60-80) for ANY KernelFunc -- the route SURVEY.md 8(b) prescribes for kernels without a
+ * device form ("any other kernel -> host-built Gram through gp_*_from_gram"): the caller evaluates, with the reference's own host
+ * loops, K = buildKernelMatrix(kernelFunc, trainingData) (:62; n x n, ld ldk, the kernel's own noise already on its diagonal) and
+ * dK[p] = buildMatrixWithFunc(trainingData)(kernelFunc.derAfterHyperParam(p + 1)) for p < nparams = optimizedParamsNum (:74; P
+ * pointers to n x n matrices with leading dimension lddk, SYMMETRIC as that builder makes them -- the lower triangles are read);
+ * the device factors K (+ sigma_noise on the diagonal, un-squared, :116; NaN = None), forms alpha and K^-1 = L^-T L^-1 (:66-67)
+ * and returns *lml and grad[p] = 1/2 tr((alpha alpha^T - K^-1) dK[p]) (:76).  Not PD -> GP_ENOTPD, *info = 1-based pivot. */
+gp_status gp_lml_grad_from_gram(gp_ctx *ctx, const double *K, int n, int ldk, const double *y, const double *const *dK, int nparams, int lddk, double sigma_noise, double *lml, double *grad, int *info);
+
 /* GpPredictor.obtainOptimalHyperParams, gp/regression/GpPredictor.scala:126-142, through
  * BreezeLbfgsOptimizer.maximize, optimization/Optimization.scala:30-63 (L-BFGS, m = history = 4, maxIter = 20 there):
  * maximises the LML over the first nparams entries of theta (optimizeNoise=false <=> nparams = d+1), starting at theta0,

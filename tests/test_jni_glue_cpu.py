@@ -1,0 +1,57 @@
+"""The JNI glue cannot be built here (no JDK in the image) -- these checks keep it honest anyway:
+  * bindings/jni/gpcore_jni.c passes `gcc -fsyntax-only -Wall -Werror` against bindings/jni/check/jni.h (a declaration-only subset
+    of the JNI types / function table with the specification's signatures) and include/gpcore.h, so every forward calls the C-ABI
+    with the right number and types of arguments;
+  * its exported Java_gpcore_Native_<name> functions and the `@native def <name>` declarations of Native.scala match one to one,
+    with the same number of parameters;
+  * every C-ABI compute entry point that has a Scala-facing use is reachable (the forwards VERDICT r02 listed as missing exist)."""
+import os
+import re
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GLUE = os.path.join(ROOT, "bindings", "jni", "gpcore_jni.c")
+NATIVE = os.path.join(ROOT, "bindings", "scala", "gpcore", "Native.scala")
+
+
+def _c_forwards():
+    src = open(GLUE).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    out = {}
+    for m in re.finditer(r"JNIEXPORT\s+\w+\s+JNICALL\s+Java_gpcore_Native_(\w+)\s*\(([^)]*)\)", src):
+        params = [p for p in m.group(2).split(",") if p.strip()]
+        out[m.group(1)] = len(params) - 2            # minus (JNIEnv *, jclass)
+    return out
+
+
+def _scala_natives():
+    src = open(NATIVE).read()
+    out = {}
+    for m in re.finditer(r"@native\s+def\s+(\w+)\s*\(([^)]*)\)", src):
+        out[m.group(1)] = len([p for p in m.group(2).split(",") if p.strip()])
+    return out
+
+
+def test_glue_is_valid_c_against_the_jni_subset_and_the_c_abi():
+    r = subprocess.run(["gcc", "-std=c11", "-fsyntax-only", "-Wall", "-Wextra", "-Wno-unused-parameter", "-Werror",
+                        "-I", os.path.join(ROOT, "bindings", "jni", "check"), "-I", os.path.join(ROOT, "include"), GLUE],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-4000:]
+
+
+def test_forwards_match_native_declarations_one_to_one():
+    c, s = _c_forwards(), _scala_natives()
+    assert len(c) >= 50
+    assert sorted(c) == sorted(s), (sorted(set(c) - set(s)), sorted(set(s) - set(c)))
+    bad = {k: (c[k], s[k]) for k in c if c[k] != s[k]}
+    assert not bad, "parameter counts differ (C, Scala): %s" % bad
+
+
+def test_forwards_named_missing_in_round_2_exist():
+    c = _c_forwards()
+    for name in ("epLmlGradRbfBatched", "smallFromFactors", "smallGet", "smallSize", "gramCo2", "dgramCo2", "crossGramCo2", "lmlGradFromGram"):
+        assert name in c, name
+    src = open(GLUE).read()
+    for sym in ("gp_ep_lml_grad_rbf_batched", "gp_small_from_factors", "gp_small_get", "gp_small_size", "gp_gram_co2", "gp_dgram_co2",
+                "gp_cross_gram_co2", "gp_lml_grad_from_gram"):
+        assert sym + "(" in src, sym
