@@ -104,10 +104,9 @@ void gemm_sub_single(hipStream_t s, int M, int N, int K, const double *A, int ld
 //       potrf_diag128(Akk) -> Lkk + 16x16 tile inverses;  A21 <- A21 Lkk^-T (MFMA trsm panel, all rows below);
 //       the rest of the OUTER PANEL's columns -= A21 A21^T (narrow MFMA update, K = 128)
 //   outer: trailing matrix -= P P^T with K = 512 (the high-intensity MFMA syrk this design is built around), one launch.
-//       Optional (ctx->lookahead, off by default): split into (a) the next outer panel's columns on the main stream
-//       and (b) everything to the right of it on the side stream, overlapping the next panel's factorisation --
-//       measured slower on MI355X (n = 8192: 11.0 vs 10.8 ms, n = 32768: 280 vs 237 ms) because the single-workgroup
-//       diagonal kernel needs a whole CU's LDS and starves behind (b)'s workgroups.
+//       Look-ahead (ctx->lookahead; by default ON for single factorisations with 4096 <= rows and np <= 16384, see below): split
+//       into (a) the next outer panel's columns on the main stream and (b) everything to the right of it on the CU-masked side
+//       stream, under the next panel's chain of single-workgroup kernels (which need a whole CU's LDS: the mask keeps CUs free).
 // `extra` (0 or GP_NB) rows below the matrix ride along: with y^T in row np this leaves (L^-1 y)^T there.
 // count > 1: a lockstep batch -- problem g lives at A + g*strideA, dinv + g*strideDinv, info + g; every launch covers all of them.
 void chol_blocked(gp_ctx *ctx, double *A, int np, int lda, double *dinv, int extra, int count = 1, size_t strideA = 0, size_t strideDinv = 0,

@@ -131,14 +131,18 @@ def test_c3_full_size_all_64_settings(ctx):
 
 
 # ---- C4 at full size -------------------------------------------------------------------------------------------------------
-def test_c4_full_size_50_sweeps(ctx):
-    """Config C4 as benchmarked: n = 4096, 50 EP sweeps (EpParameterEstimator.scala:29-69)."""
+@pytest.mark.parametrize("jitter", [0.0, 1e-6])
+def test_c4_full_size_50_sweeps(ctx, jitter):
+    """Config C4: n = 4096, 50 EP sweeps (EpParameterEstimator.scala:29-69).  jitter = 0 is the matrix bench.py --workload c4 runs
+    (BASELINE C4: sigma_n = 0, so K is only positive SEMI-definite in floating point -- EP never factors K, only
+    B = I + S^1/2 K S^1/2, and every identity below holds for a semi-definite K); 1e-6 is the well-conditioned copy kept from
+    round 2."""
     from gp_algos_amd import _lib as L
     from gp_algos_amd.core import EpClassifierState
     n = 4096
     p = synth.config_c4(n, 8)
-    K = ctx.gram_rbf(p["X"], p["theta"])
-    K[np.diag_indices_from(K)] += 1e-6     # the C4 kernel has sn = 0: keep K numerically PD for the host-side identity
+    K = ctx.gram_rbf(p["X"], p["theta"], full=True)      # exactly what bench.py hands to gp_ep_create
+    K[np.diag_indices_from(K)] += jitter
     ep = EpClassifierState(ctx, K, p["y"])
     tau, nu = ep.sweep(50)
     assert np.all(np.isfinite(tau)) and np.all(np.isfinite(nu)) and np.all(tau > 0)

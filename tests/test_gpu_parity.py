@@ -371,6 +371,32 @@ def test_ep_sweeps_vs_oracle(ctx, n, sweeps):
     ep.close()
 
 
+@pytest.mark.parametrize("n,pipeline,block", [(300, "0", "1"), (300, "1", "1"), (300, "1", "0"), (420, "1", "1")])
+def test_ep_50_sweeps_vs_oracle(ctx, monkeypatch, n, pipeline, block):
+    """BASELINE config C4's sweep count against the LITERAL rank-1 loop of EpParameterEstimator.scala:40-62:
+    the delayed rank-128 form must not drift from it over 50 sweeps -- site parameters, mean, covariance and factor at TOL_EP
+    (1e-8, the tolerance BASELINE.md states), in both refactorisation forms and with both block kernels."""
+    from gp_algos_amd import _lib as L
+    from gp_algos_amd.core import EpClassifierState
+    monkeypatch.setenv("GPCORE_EP_PIPELINE", pipeline)
+    monkeypatch.setenv("GPCORE_EP_BLOCK", block)
+    p, K, y = _ep_problem(n, seed=3 * n)
+    o = orc.ep_estimate(K, y, 50)
+    assert o["sweeps"] == 50
+    ep = EpClassifierState(ctx, K, y)
+    tau, nu = ep.sweep(20)
+    tau, nu = ep.sweep(30)               # two calls: 50 sweeps in all
+    drift = {"tau": np.max(np.abs(tau - o["tau"])) / np.max(np.abs(o["tau"])), "nu": np.max(np.abs(nu - o["nu"])) / np.max(np.abs(o["nu"]))}
+    for key, sel in (("mu", L.GP_EP_GET_MU), ("Sigma", L.GP_EP_GET_SIGMA), ("L", L.GP_EP_GET_L)):
+        drift[key] = np.max(np.abs(ep.get(sel) - o[key])) / np.max(np.abs(o[key]))
+    print("EP 50 sweeps n=%d pipeline=%s block=%s drift vs literal rank-1 loop: %s" % (n, pipeline, block, {k: "%.2e" % v for k, v in drift.items()}))
+    assert all(v <= TOL_EP for v in drift.values()), drift
+    for strict in (True, False):
+        ol = orc.ep_lml(o, y, strict=strict)
+        assert abs(ep.lml(strict=strict) - ol) <= 1e-9 * max(1.0, abs(ol))
+    ep.close()
+
+
 @pytest.mark.parametrize("n,sweeps", [(200, 2), (300, 3), (640, 2), (700, 3), (1600, 2)])   # 1600: far trailing updates on their own stream
 def test_ep_streamed_refactorisation_vs_oracle_and_end_of_sweep_form(ctx, monkeypatch, n, sweeps):
     """The refactorisation of EpParameterEstimator.scala:56-61 run UNDER the site loop (default from n = 1024; forced here)
