@@ -14,6 +14,7 @@
 // the blocked Cholesky, the row-panel solve and the MFMA syrk of the regression path.
 #include "gpcore_internal.h"
 #include "dpp_tile.h"
+#include "trsm_tile.h"
 
 #include <algorithm>
 #include <atomic>
@@ -40,6 +41,8 @@ struct gp_ep {
     std::vector<hipEvent_t> ev;   // 4 per block: block factor ready | next block's rows solved | side-stream update done | Vt block column final
     hipEvent_t ev_chol = nullptr, ev_parta = nullptr, ev_partb = nullptr;   // end-of-sweep refactorisation: see ep_refactor
     hipEvent_t ev_w = nullptr, ev_pipe = nullptr;   // streamed refactorisation: sweep start on the main stream | its last launch
+    int *flags = nullptr;         // np/128 device flags (+ 1 error word): "solved rows of block b are in memory" (ep_block2_kernel -> side stream)
+    int epoch = 0;                // token of the current sweep's flags; never reset, so a stale flag cannot match
     bool side_pending = false;    // the side stream still owes the second part of Sigma / mu
     bool sig_mirrored = false;    // the strict upper triangle of Sig mirrors the lower one (only gp_ep_get needs it)
     int *y = nullptr;
@@ -55,8 +58,6 @@ struct gp_ep {
     double *tmp1() { return vec + 8 * (size_t)np; }
     double *tmp2() { return vec + 9 * (size_t)np; }
 };
-
-typedef double double4_t __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -559,6 +560,246 @@ __global__ __launch_bounds__(64 * EP_BLOCK1_WAVES) void ep_block1_kernel(int n, 
     }
 }
 
+// ---- the fused chain kernel: link to the block before + all site updates of this block, ONE launch per block ----
+// Between two block kernels the sweep used to run a second single-workgroup kernel (ep_link_kernel: the 128 rows of the previous
+// block's delayed columns that belong to this block, X = Sigma0[blk b, blk b-1] Lmat^-T, and the diagonal tile
+// D = Sigma0[blk b, blk b] -= X diag(c) X^T this block's site loop starts from).  Everything the link produces for the CHAIN stays
+// on one CU, so it is this kernel's prologue: the X strip is solved in the LDS the site loop has not started to use yet, the 36
+// lower tiles of D are updated in registers and dropped straight into the site loop's LDS image (they never go back to global
+// memory: Sigma[blk b, blk b] is dead after this block), the mean update lands in the staged mean.  One launch, one launch gap,
+// the D round trip through L2 (66 KB out, 128 KB in) and the block kernel's own load of A are gone from the chain.
+// What OTHER streams need from the link -- the solved rows X (in place in Sigma's dead panel: the other operand of the
+// column-panel update below this block's diagonal tile) -- is stored from the prologue while the matrix cores run the tile
+// update, and announced by a device flag (release, agent scope) as soon as every wave's stores have been acknowledged: the side
+// stream's consumer is preceded by ep_wait_flag_kernel, so it starts ~25 us into this kernel instead of after its ~100 us.
+// blockIdx.x = problem of a lockstep batch (ep_strides; a single run has one).
+struct ep_strides {
+    size_t sig = 0, vec = 0, y = 0, blk = 0, cvec = 0;   // in elements, per problem
+    int flag = 0;
+};
+constexpr int EP2_XS = 144;   // LDS column stride of the prologue's 128-row strip: 1152 B = 128 (mod 256) -> conflict-free fragments
+constexpr int EP_BLOCK2_LDS = (GP_NB * EP2_XS + 8 * GP_NB + 5 * GP_NB + 16) * (int)sizeof(double);   // 160 896 B of the CU's 163 840
+constexpr int EP_BLK_ELEMS = GP_NB * GP_NB + 8 * 256;   // Lmat + its tile inverses
+
+template <bool PRO>
+__global__ __launch_bounds__(64 * EP_BLOCK1_WAVES) void ep_block2_kernel(int n, int np, int i0, int bsz, double *__restrict__ Sig,
+                                                                        double *__restrict__ vec, const int *__restrict__ y,
+                                                                        double *__restrict__ blk, double *__restrict__ cvbase,
+                                                                        int *__restrict__ flags, int par, int token, ep_strides es) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    constexpr int LS = GP_NB + 1;
+    Sig += (size_t)blockIdx.x * es.sig, vec += (size_t)blockIdx.x * es.vec, y += (size_t)blockIdx.x * es.y;
+    blk += (size_t)blockIdx.x * es.blk, cvbase += (size_t)blockIdx.x * es.cvec;
+    flags += (size_t)blockIdx.x * es.flag;
+    double *tau = vec, *nu = vec + np, *cav_tau = vec + 5 * (size_t)np, *cav_nu = vec + 6 * (size_t)np;
+    const double *mu = vec + 4 * (size_t)np;
+    double *Lmat = blk + (size_t)par * EP_BLK_ELEMS, *Ldinv = Lmat + GP_NB * GP_NB;
+    double *cvec = cvbase + (size_t)par * 2 * GP_NB, *ncoef = cvec + GP_NB;
+    double *A = sm;                          // column c: Sigma0[blk, i0+c] until site c is processed, afterwards s_c[blk]
+    double *xs = sm;                         // prologue only: the X strip, 128 x EP2_XS (overlaps A: A is written after the strip is dead)
+    double *cs = sm + GP_NB * EP2_XS;        // c
+    double *cf = cs + GP_NB;                 // coef
+    double *mb = cf + GP_NB;                 // mu restricted to the block (staging only)
+    double *tb = mb + GP_NB;                 // site parameters and labels, staged once
+    double *nb = tb + GP_NB;
+    double *yb = nb + GP_NB;
+    double *ob = yb + 3 * GP_NB;             // [site][5]: 1/sii, tau_old, sg, mi, cavity nu
+    const int tid = threadIdx.x, r = tid, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
+    const bool rowthread = tid < GP_NB;
+    if (rowthread) {
+        cs[r] = 0.0;
+        cf[r] = 0.0;
+        const bool live = r < bsz;
+        tb[r] = live ? tau[i0 + r] : 0.0;
+        nb[r] = live ? nu[i0 + r] : 0.0;
+        yb[r] = live ? (double)y[i0 + r] : 0.0;
+    }
+    if constexpr (PRO) {
+        const double *pL = blk + (size_t)(1 - par) * EP_BLK_ELEMS, *pdinv = pL + GP_NB * GP_NB;     // the block before: unit-lower factor,
+        const double *pc = cvbase + (size_t)(1 - par) * 2 * GP_NB, *pcoef = pc + GP_NB;             //   its tile inverses, c and coef
+        double *X = Sig + i0 + (size_t)(i0 - GP_NB) * np;      // rows of this block, columns of the block before (solved in place)
+        const double *D = Sig + i0 + (size_t)i0 * np;
+        {   // strip by LDS-DMA: one wave instruction = one 128-row column (1 KiB), 32 per wave, all in flight
+            const double *src = X + lane * 2 + (size_t)wave * np;
+#pragma unroll
+            for (int q = 0; q < GP_NB / 4; ++q) __builtin_amdgcn_global_load_lds(src + (size_t)(4 * q) * np, xs + (wave + 4 * q) * EP2_XS, 16, 0, 0);
+        }
+        // this wave's nine lower tiles of D (q = wave, wave + 4, ...): fetched under the solve
+        double4_t dacc[9];
+#pragma unroll
+        for (int u = 0; u < 9; ++u) {
+            int I, J;
+            tri_coords(wave + 4 * u, I, J);
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) dacc[u][rr] = D[(16 * I + fr) + (size_t)(16 * J + fg + 4 * rr) * np];
+        }
+        double fa[28], fb[28];
+        trsm_load_frags<1>(pL, GP_NB, fr, fg, fa);
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the DMA has landed (and the loads above)
+        __syncthreads();
+        // X <- X Lmat^-T: rows are independent, every wave solves its own 32 (two 16-row sub-strips share the L fragments)
+        const int sp0 = wave * 32 + fr, sp1 = sp0 + 16;
+        double ss = 0.0;
+#define EP2_CHUNK(CB, F) do { trsm_chunk<CB, EP2_XS>(xs, sp0, fr, fg, F, pdinv, ss); trsm_chunk<CB, EP2_XS>(xs, sp1, fr, fg, F, pdinv, ss); } while (0)
+        trsm_load_frags<2>(pL, GP_NB, fr, fg, fb);
+        EP2_CHUNK(0, fa);
+        EP2_CHUNK(1, fa);
+        trsm_load_frags<3>(pL, GP_NB, fr, fg, fa);
+        EP2_CHUNK(2, fb);
+        trsm_load_frags<4>(pL, GP_NB, fr, fg, fb);
+        EP2_CHUNK(3, fa);
+        trsm_load_frags<5>(pL, GP_NB, fr, fg, fa);
+        EP2_CHUNK(4, fb);
+        trsm_load_frags<6>(pL, GP_NB, fr, fg, fb);
+        EP2_CHUNK(5, fa);
+        trsm_load_frags<7>(pL, GP_NB, fr, fg, fa);
+        EP2_CHUNK(6, fb);
+        EP2_CHUNK(7, fa);
+#undef EP2_CHUNK
+        (void)ss;
+        __syncthreads();
+        {   // the solved rows go out now (the side stream's column-panel update multiplies by them; their scaled copy is only ever
+            // used by the tile update below, which scales on the fly): the stores drain while the matrix cores run that update
+            const int li = lane * 2, lc = wave;
+#pragma unroll 8
+            for (int q = 0; q < GP_NB / 4; ++q) {
+                const int c = lc + 4 * q;
+                *reinterpret_cast<double2_t *>(X + li + (size_t)c * np) = *reinterpret_cast<const double2_t *>(xs + c * EP2_XS + li);
+            }
+        }
+        if (rowthread) {   // mean of this block's rows: + X coef of the block before (the O(n) form of mu = Sigma nu, Appendix A.3)
+            double acc = 0.0;
+#pragma unroll 8
+            for (int c = 0; c < GP_NB; ++c) acc = fma(xs[c * EP2_XS + r], pcoef[c], acc);
+            mb[r] = ((i0 + r < n) ? mu[i0 + r] : 0.0) + acc;
+        }
+        // D(lower) -= X diag(c) X^T: nine tiles per wave, K = 128, operands from the strip
+#pragma unroll
+        for (int u = 0; u < 9; ++u) {
+            int I, J;
+            tri_coords(wave + 4 * u, I, J);
+            double4_t acc = dacc[u];
+#pragma unroll 8
+            for (int ks = 0; ks < 32; ++ks) {
+                const int k = 4 * ks + fg;
+                const double aop = -(pc[k] * xs[k * EP2_XS + 16 * J + fr]);
+                const double bop = xs[k * EP2_XS + 16 * I + fr];
+                acc = MFMA(aop, bop, acc);
+            }
+            dacc[u] = acc;
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // this wave's stores of X / X2 are acknowledged
+        __syncthreads();                      // ... and nobody reads the strip any more
+        // the site loop's image of the block: lower tiles from the accumulators, the strictly upper tiles (never used) cleared
+#pragma unroll
+        for (int u = 0; u < 9; ++u) {
+            int I, J;
+            tri_coords(wave + 4 * u, I, J);
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) A[(16 * I + fr) + (16 * J + fg + 4 * rr) * LS] = dacc[u][rr];
+        }
+        for (int e = tid; e < GP_NB * GP_NB; e += 64 * EP_BLOCK1_WAVES) {
+            const int rr = e & (GP_NB - 1), cc = e >> 7;
+            if ((rr >> 4) < (cc >> 4)) A[rr + cc * LS] = 0.0;
+        }
+        if (tid == 64) {   // one lane announces X / X2 (every wave has waited for its stores before the barrier above)
+            __threadfence();
+            __hip_atomic_store(flags + i0 / GP_NB, token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    } else {
+        // first block of a sweep: the block of Sigma0 as it stands, every thread half of a row's columns, 16 loads in flight
+        const int rr = tid & (GP_NB - 1), cq0 = 64 * (tid >> 7);
+#pragma unroll
+        for (int c0 = 0; c0 < 64; c0 += 16) {
+            double v[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) v[c] = Sig[(i0 + rr) + (size_t)(i0 + cq0 + c0 + c) * np];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) A[rr + (cq0 + c0 + c) * LS] = v[c];
+        }
+        if (rowthread) mb[r] = (i0 + r < n) ? mu[i0 + r] : 0.0;
+    }
+    __syncthreads();
+    const int jtiles = (bsz + 15) >> 4;
+    ep_site_regs st;
+    if (wave == 0) {
+        st.m0 = mb[lane], st.m1 = mb[lane + 64];
+        st.sp0 = st.sp1 = 0.0, st.c_prev = st.coef_prev = 0.0;
+    }
+    for (int ch = 0; ch < jtiles; ++ch) {
+        const int cs0 = 16 * ch;
+        if (wave == 0) {
+            st.p0 = A[lane + cs0 * LS];          // the chunk's first column is final as it stands (the boundary tiles applied every earlier site)
+            st.p1 = A[lane + 64 + cs0 * LS];
+            const int c1 = cs0 + 1 < GP_NB ? cs0 + 1 : cs0;
+            st.a0 = A[lane + c1 * LS], st.a1 = A[lane + 64 + c1 * LS];
+            st.to_n = tb[cs0], st.no_n = nb[cs0], st.yi_n = yb[cs0];
+            const bool full = cs0 + 16 <= bsz;
+            if (cs0 < 64) {
+                if (full) ep_site_steps<0, false, true>(st, A, cs, cf, ob, tb, nb, yb, cs0, bsz, lane);
+                else ep_site_steps<0, false, false>(st, A, cs, cf, ob, tb, nb, yb, cs0, bsz, lane);
+            } else {
+                if (full) ep_site_steps<0, true, true>(st, A, cs, cf, ob, tb, nb, yb, cs0, bsz, lane);
+                else ep_site_steps<0, true, false>(st, A, cs, cf, ob, tb, nb, yb, cs0, bsz, lane);
+            }
+        } else if (ch > 0) {
+            int k = wave - 1;
+            for (int J = ch + 1; J < jtiles; ++J)
+                for (int I = J; I < 8; ++I, k = (k == 0 ? EP_BLOCK1_WAVES - 2 : k - 1))
+                    if (k == 0) ep_chunk_tile(A, cs, LS, I, J, cs0 - 16, fr, fg);
+        }
+        __syncthreads();
+        if (ch + 1 < jtiles) {
+            const int jc = ch + 1;
+            for (int I = jc + wave; I < 8; I += EP_BLOCK1_WAVES) ep_chunk_tile(A, cs, LS, I, jc, cs0, fr, fg);
+            __syncthreads();
+        }
+    }
+    // outputs of all sites (:45-51 as written), one thread per site
+    if (rowthread && r < bsz) {
+        const double *o = ob + 5 * r;
+        const double tc = o[0] - o[1];                              // cavity tau  :45
+        const double isg = rcp_nr(o[2]);
+        const double dtau = isg - tc - o[1];                        // :49
+        tau[i0 + r] = o[1] + dtau;                                  // :50
+        nu[i0 + r] = o[3] * isg - o[4];                             // :51
+        cav_tau[i0 + r] = tc;
+        cav_nu[i0 + r] = o[4];
+        cvec[r] = cs[r];
+        ncoef[r] = cf[r];
+    }
+    if (rowthread) {
+        if (r >= bsz) { cvec[r] = 0.0; ncoef[r] = 0.0; }
+        for (int c = 0; c < GP_NB; ++c)
+            Lmat[r + (size_t)c * GP_NB] = (r == c) ? 1.0 : ((r > c && c < bsz) ? A[r + c * LS] * cs[c] : 0.0);
+    }
+    if (wave == 2 || wave == 3) {   // unit-lower tile inverses of Lmat, as in ep_block_kernel
+        const int c0 = 16 * (4 * (wave - 2) + fg);
+        double row[16], sv[16], x[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            row[k] = (c0 + k < bsz) ? A[(c0 + fr) + (c0 + k) * LS] * cs[c0 + k] : 0.0;
+            sv[k] = (k == fr) ? 1.0 : 0.0;
+        }
+        tile_unit_inverse<0>(row, sv, x);
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) Ldinv[(c0 / 16) * 256 + rr + 16 * fr] = x[rr];
+    }
+}
+
+// One thread per problem waits for the flag ep_block2_kernel sets when the solved rows of block `b` are in memory.  The wait is
+// BOUNDED: the producer was launched before this kernel and depends on nothing that comes after it (gp_ep_sweep), so the flag
+// arrives within the producer's first ~25 us; if it has not arrived after ~0.2 s something else is wrong, the kernel gives up,
+// records it in *err and the sweep returns GP_EHIP -- a loud failure instead of a hung queue.
+__global__ void ep_wait_flag_kernel(const int *__restrict__ flags, int stride, int token, int *__restrict__ err) {
+    const int *f = flags + (size_t)blockIdx.x * stride;
+    int it = 0;
+    while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != token) {
+        if (++it > 200000) { atomicExch(err, 1 + (int)blockIdx.x); break; }
+        __builtin_amdgcn_s_sleep(32);
+    }
+}
+
 // D (128 x 128, lower triangle, leading dimension ldd) -= Sc St^T with Sc, St the 128 x 128 row blocks (leading dimension ld)
 // of the scaled and unscaled delayed columns: the ONE tile of a block's rank-128 update that the next block kernel reads.
 // It sits on the serial chain of the sweep, where the general 128 x 128-tile GEMM would run it on a single CU (14 us of
@@ -833,6 +1074,8 @@ gp_status ep_alloc(gp_ctx *ctx, int n, const int32_t *y, gp_ep **out) {
     GP_HIP(ctx, hipSetDevice(ctx->device));
     GP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(ep_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, EP_BLOCK_LDS));
     GP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(ep_block1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, EP_BLOCK1_LDS));
+    GP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(ep_block2_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, EP_BLOCK2_LDS));
+    GP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(ep_block2_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, EP_BLOCK2_LDS));
     gp_ep *ep = new (std::nothrow) gp_ep();
     if (!ep) return GP_ENOMEM;
     ep->ctx = ctx; ep->n = n; ep->np = gp_pad(n); ep->ldl = 2 * ep->np;
@@ -855,7 +1098,9 @@ gp_status ep_alloc(gp_ctx *ctx, int n, const int32_t *y, gp_ep **out) {
     for (hipEvent_t &ev : ep->ev)
         if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc(&ep->y, np * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc(&ep->flags, (np / GP_NB + 1) * sizeof(int));
     hipStream_t s = ctx->stream;
+    if (e == hipSuccess) e = hipMemsetAsync(ep->flags, 0, (np / GP_NB + 1) * sizeof(int), s);
     if (e == hipSuccess) e = hipMemsetAsync(ep->K, 0, nn, s);
     if (e == hipSuccess) e = hipMemsetAsync(ep->L, 0, 2 * nn, s);
     if (e == hipSuccess) e = hipMemsetAsync(ep->y, 0, np * sizeof(int), s);
@@ -919,6 +1164,14 @@ gp_status gp_ep_sweep(gp_ep *ep, int nsweeps, double *tau, double *nu, int *info
     // under the streamed refactorisation's GEMMs the fused one is (167.4 vs 163.9) -- so it follows `pipe` (GPCORE_EP_LINK overrides)
     const bool fused_link = [pipe] { const char *e = getenv("GPCORE_EP_LINK"); return e ? atoi(e) != 0 : pipe; }();
     const bool block1 = [] { const char *e = getenv("GPCORE_EP_BLOCK"); return !e || atoi(e) != 0; }();   // site loop on one wave (0: one barrier per site)
+    // GPCORE_EP_FUSED: the link of block b-1 is the prologue of block b's kernel (ep_block2_kernel) -- one launch per block on the
+    // chain; 0: block kernel + link kernel (the form it is tested against, bit for bit).  Measured (sweeps/s fused / two launches):
+    // n = 4096 181.0 / 182.1, n = 2048 425.5 / 411.8, n = 1024 627.0 / 668.3 -- the prologue costs what the link kernel did (34 us:
+    // profiles/r03_c_sweep_fused.txt), the chain is as much bound by the side stream's solve + updates as by its own kernels, so
+    // the default follows the streamed refactorisation (np > 1024); the lockstep batch (ep_sweep_lockstep) always uses it
+    const bool fused = overlap && block1 && [pipe] { const char *e = getenv("GPCORE_EP_FUSED"); return e ? atoi(e) != 0 : pipe; }();
+    int *flag_err = ep->flags + np / GP_NB;
+    if (fused) GP_HIP(ctx, hipMemsetAsync(flag_err, 0, sizeof(int), s));
     const bool far_split = [] { const char *e = getenv("GPCORE_EP_FAR"); return !e || atoi(e) != 0; }();
     // columns of Vt per next-covariance update (GPCORE_EP_SIG_K; n = 4096 sweeps/s at 128 / 256 / 384 / 512 / 1024 / 2048: 173 / 181 / 175 / 177 /
     // 172 / 155 -- short enough to spread the fourth stream's load evenly, long enough for the GEMM)
@@ -936,6 +1189,7 @@ gp_status gp_ep_sweep(gp_ep *ep, int nsweeps, double *tau, double *nu, int *info
         GP_TRY(gpi_ws_get(ctx, WS_PARTIAL, sizeof(double) * (size_t)(SYMV_CHUNKS + 1) * np, &partial));
     }
     for (int sw = 0; sw < nsweeps; ++sw) {
+        const int token = ++ep->epoch;
         // Only the TRAILING part of the recurrence is carried: the sites after a block read mu_i and Sigma_ii "as of now",
         // which depend on the earlier blocks through rows/columns >= their own block only, and the end-of-sweep
         // refactorisation (:56-61) rebuilds Sigma and mu from the site parameters anyway.  So the delayed columns
@@ -972,7 +1226,16 @@ gp_status gp_ep_sweep(gp_ep *ep, int nsweeps, double *tau, double *nu, int *info
             const int par = b & 1;
             double *Lmat = ep->blk + (size_t)par * (GP_NB * GP_NB + 8 * 256), *bdinv = Lmat + GP_NB * GP_NB;
             double *cvec = ep->cvec + (size_t)par * 2 * GP_NB, *ncoef = cvec + GP_NB;   // c and coef of every site of the block
-            if (block1)
+            if (fused) {
+                // the prologue reads Sigma[blk b, blk b-1 .. b]: entries the side stream's update of block b-2 wrote
+                if (b >= 2) GP_HIP(ctx, hipStreamWaitEvent(s, ep->ev[4 * (b - 2) + 2], 0));
+                if (b > 0)
+                    hipLaunchKernelGGL(ep_block2_kernel<true>, dim3(1), dim3(64 * EP_BLOCK1_WAVES), EP_BLOCK2_LDS, s, n, np, i0, bsz, ep->Sig, ep->vec,
+                                       ep->y, ep->blk, ep->cvec, ep->flags, par, token, ep_strides());
+                else
+                    hipLaunchKernelGGL(ep_block2_kernel<false>, dim3(1), dim3(64 * EP_BLOCK1_WAVES), EP_BLOCK2_LDS, s, n, np, i0, bsz, ep->Sig, ep->vec,
+                                       ep->y, ep->blk, ep->cvec, ep->flags, par, token, ep_strides());
+            } else if (block1)
                 hipLaunchKernelGGL(ep_block1_kernel, dim3(1), dim3(64 * EP_BLOCK1_WAVES), EP_BLOCK1_LDS, s, n, np, i0, bsz, ep->Sig, ep->mu(), ep->y,
                                    ep->tau(), ep->nu(), ep->cav_tau(), ep->cav_nu(), cvec, ncoef, Lmat, bdinv);
             else
@@ -1001,6 +1264,19 @@ gp_status gp_ep_sweep(gp_ep *ep, int nsweeps, double *tau, double *nu, int *info
                     pend0 = i0 + GP_NB;
                 }
             }
+            if (fused && b > 0) {
+                // side stream, part 2 of block b-1: the column panel of block b below its diagonal tile.  It needs the rows this
+                // kernel's prologue has just solved: announced by a device flag, awaited by a one-thread kernel (enqueued AFTER the
+                // producer, which depends on nothing later on any stream; the wait is bounded and reports instead of hanging)
+                const int prest = np - i0 - GP_NB;           // rows from block b+1 on
+                if (prest > 0) {
+                    hipLaunchKernelGGL(ep_wait_flag_kernel, dim3(1), dim3(1), 0, s2, ep->flags + b, 0, token, flag_err);
+                    const double *pSt = ep->Sig + (size_t)i0 + (size_t)(i0 - GP_NB) * np, *pSct = ep->Sc + i0;
+                    gpk_gemm_nt(s2, prest, GP_NB, GP_NB, -1.0, pSct + GP_NB, np, pSt, np, 1.0, ep->Sig + (size_t)(i0 + GP_NB) + (size_t)i0 * np, np, 0);
+                }
+                GP_HIP(ctx, hipEventRecord(ep->ev[4 * (b - 1) + 2], s2));
+                last_side = ep->ev[4 * (b - 1) + 2];
+            }
             const int r0 = i0 + GP_NB, rt = np - r0;
             if (rt <= 0 || r0 >= n) continue;
             double *St = ep->Sig + (size_t)r0 + (size_t)i0 * np, *Sct = ep->Sc + r0;
@@ -1021,6 +1297,7 @@ gp_status gp_ep_sweep(gp_ep *ep, int nsweeps, double *tau, double *nu, int *info
                 gpk_gemm_nt(s2, rest, rest, GP_NB, -1.0, Sct + GP_NB, np, St + GP_NB, np, 1.0, Ctr + GP_NB + (size_t)GP_NB * np, np, 1);
                 gp_prof_end(ctx, GP_PROF_GEMM, (double)rest * ((double)rest + GP_NB) * GP_NB, s2);
             }
+            if (fused) continue;     // the link is the next block kernel's prologue, part 2 follows its flag (above)
             // main stream: the 128 rows of block b+1 -- they read Sigma entries the side stream's update of block b-1 wrote
             if (b > 0) GP_HIP(ctx, hipStreamWaitEvent(s, ep->ev[4 * (b - 1) + 2], 0));
             if (fused_link) gpk_ep_link(s, St, np, Lmat, bdinv, ncoef, ep->mu() + r0, Sct, cvec, Ctr, np);
@@ -1055,6 +1332,11 @@ gp_status gp_ep_sweep(gp_ep *ep, int nsweeps, double *tau, double *nu, int *info
     GP_TRY(ep_join_side(ep));
     int h = 0;
     GP_TRY(gpi_read_info(ctx, &h));
+    if (fused) {
+        int ferr = 0;
+        GP_HIP(ctx, hipMemcpy(&ferr, flag_err, sizeof(int), hipMemcpyDeviceToHost));
+        if (ferr) { GP_SET_ERR(ctx, "EP sweep: a device flag of the fused chain did not arrive within its bound (problem %d)", ferr - 1); return GP_EHIP; }
+    }
     if (info) *info = h;
     if (h) { GP_SET_ERR(ctx, "I + S^1/2 K S^1/2 not positive definite at pivot %d (negative site precision?)", h); return GP_ENOTPD; }
     if (tau) GP_TRY(gpi_download_2d(ctx, tau, n, ep->tau(), np, n, 1));
@@ -1333,7 +1615,7 @@ void gp_ep_destroy(gp_ep *ep) {
     }
     for (hipEvent_t ev : ep->ev) if (ev) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : {ep->ev_chol, ep->ev_parta, ep->ev_partb, ep->ev_w, ep->ev_pipe}) if (ev) (void)hipEventDestroy(ev);
-    void *ptrs[] = {ep->K, ep->Sig, ep->Sig2, ep->L, ep->dinv, ep->S, ep->Sc, ep->blk, ep->vec, ep->cvec, ep->y};
+    void *ptrs[] = {ep->K, ep->Sig, ep->Sig2, ep->L, ep->dinv, ep->S, ep->Sc, ep->blk, ep->vec, ep->cvec, ep->y, ep->flags};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete ep;
 }

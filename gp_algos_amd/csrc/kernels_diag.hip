@@ -16,15 +16,13 @@
 // everything larger is substitution, so the backward error stays at the substitution level.
 #include "gpcore_internal.h"
 #include "dpp_tile.h"
-
-typedef double double4_t __attribute__((ext_vector_type(4)));
-typedef double double2_t __attribute__((ext_vector_type(2)));
+#include "trsm_tile.h"
 
 namespace {
 
 constexpr int NB = GP_NB;   // 128
+constexpr int XS = TRSM_XS;
 constexpr int PLS = 144;    // LDS column stride of the 128x128 block: 1152 B = 128 (mod 256) -> conflict-free fragments
-constexpr int XS = 80;      // LDS column stride of the 64-row X strip: 640 B = 128 (mod 256)
 constexpr int LS1 = NB + 1;
 #ifndef POTRF_DPP
 #define POTRF_DPP 1   // 16 x 16 tile factorisation with DPP row broadcasts (0: v_readlane / LDS-broadcast form)
@@ -38,8 +36,6 @@ __device__ __forceinline__ double rl64(double v, int lane) {
     int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
     return __hiloint2double(hi, lo);
 }
-
-#define MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 
 // Column J of the 16 x 16 tile Cholesky (row owner = lane & 15, replicated in the four 16-lane rows of the wave) together
 // with step J of the tile inverse X = L^-1 (column owner = lane & 15).  Both are chains of DEPENDENT fp64 operations
@@ -106,13 +102,6 @@ __device__ unsigned long long potrf_stamps[256];
 #endif
 
 // -------------------------------------------------------------------------------------------------
-// tile index q of a lower-triangular enumeration -> (bi, bj), bi >= bj
-__device__ __forceinline__ void tri_coords(int q, int &bi, int &bj) {
-    bi = 0;
-    while ((bi + 1) * (bi + 2) / 2 <= q) ++bi;
-    bj = q - bi * (bi + 1) / 2;
-}
-
 constexpr int POTRF_WAVES = 8;   // wave 0: the serial chain; the others: panel, update and stores (two waves per SIMD hide each other's LDS / MFMA latency)
 __global__ __launch_bounds__(64 * POTRF_WAVES) void potrf_diag128_kernel(double *__restrict__ A, int lda, double *__restrict__ dinv,
                                                             int *info, int base, gp_batch bt) {
@@ -252,41 +241,6 @@ __global__ __launch_bounds__(64 * POTRF_WAVES) void potrf_diag128_kernel(double 
 }
 
 // -------------------------------------------------------------------------------------------------
-// L fragments of chunk CB (rows 16*CB.., all previous columns): 4*CB values per lane, A-operand layout.
-template <int CB>
-__device__ __forceinline__ void trsm_load_frags(const double *__restrict__ L, int ldl, int fr, int fg, double (&lf)[28]) {
-#pragma unroll
-    for (int q = 0; q < 4 * CB; ++q) lf[q] = L[(16 * CB + fr) + (size_t)(4 * q + fg) * ldl];
-}
-
-// one 16-column chunk: R = B_cb - X_prev L(cb,prev)^T on the matrix cores, then X_cb = invD_cb R with the
-// accumulator registers fed straight back as the B operand (register r carries k = fg + 4r).
-template <int CB, int XS = ::XS>
-__device__ __forceinline__ void trsm_chunk(double *xs, int sp, int fr, int fg, const double (&lf)[28],
-                                           const double *__restrict__ dinv, double &ss) {
-    constexpr int c0 = 16 * CB;
-    double4_t acc0, acc1 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int r = 0; r < 4; ++r) acc0[r] = xs[(c0 + fg + 4 * r) * XS + sp];
-    double dq[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) dq[r] = dinv[CB * 256 + fr + 16 * (fg + 4 * r)];
-#pragma unroll
-    for (int q = 0; q < 4 * CB; q += 2) {
-        acc0 = MFMA(-lf[q], xs[(4 * q + fg) * XS + sp], acc0);
-        acc1 = MFMA(-lf[q + 1], xs[(4 * q + 4 + fg) * XS + sp], acc1);
-    }
-    acc0 += acc1;
-    double4_t nw = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int r = 0; r < 4; ++r) nw = MFMA(dq[r], acc0[r], nw);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        xs[(c0 + fg + 4 * r) * XS + sp] = nw[r];
-        ss = fma(nw[r], nw[r], ss);
-    }
-}
-
 template <bool SCALED_COPY>
 __global__ __launch_bounds__(256, 2) void trsm_panel128_kernel(double *__restrict__ X, int ldx, const double *__restrict__ L, int ldl,
                                                              const double *__restrict__ dinv, double *__restrict__ sumsq,

@@ -397,6 +397,29 @@ def test_ep_50_sweeps_vs_oracle(ctx, monkeypatch, n, pipeline, block):
     ep.close()
 
 
+@pytest.mark.parametrize("n,pipeline", [(130, "0"), (300, "0"), (700, "1"), (1100, "1"), (1600, "1")])
+def test_ep_fused_chain_kernel_is_the_same_sweep(ctx, monkeypatch, n, pipeline):
+    """ep_block2_kernel (the link of block b-1 as the prologue of block b's kernel, the side stream released by a device flag)
+    against block kernel + link kernel: the same arithmetic in the same order -> the same bits; both against the oracle."""
+    from gp_algos_amd import _lib as L
+    from gp_algos_amd.core import EpClassifierState
+    p, K, y = _ep_problem(n, seed=n + 11)
+    monkeypatch.setenv("GPCORE_EP_PIPELINE", pipeline)
+    got = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("GPCORE_EP_FUSED", fused)
+        ep = EpClassifierState(ctx, K, y)
+        tau, nu = ep.sweep(2)
+        tau, nu = ep.sweep(2)
+        got[fused] = dict(tau=tau, nu=nu, mu=ep.get(L.GP_EP_GET_MU), Sigma=ep.get(L.GP_EP_GET_SIGMA), L=ep.get(L.GP_EP_GET_L), lml=ep.lml(strict=False))
+        ep.close()
+    o = orc.ep_estimate(K, y, 4)
+    for key in ("tau", "nu", "mu", "Sigma", "L"):
+        assert np.array_equal(got["1"][key], got["0"][key]), key
+        assert np.max(np.abs(got["1"][key] - o[key])) <= TOL_EP * np.max(np.abs(o[key])), key
+    assert got["1"]["lml"] == got["0"]["lml"]
+
+
 @pytest.mark.parametrize("n,sweeps", [(200, 2), (300, 3), (640, 2), (700, 3), (1600, 2)])   # 1600: far trailing updates on their own stream
 def test_ep_streamed_refactorisation_vs_oracle_and_end_of_sweep_form(ctx, monkeypatch, n, sweeps):
     """The refactorisation of EpParameterEstimator.scala:56-61 run UNDER the site loop (default from n = 1024; forced here)
