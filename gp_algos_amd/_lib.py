@@ -6,7 +6,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgpcore.so")
+LIB_PATH = os.environ.get("GPCORE_LIB_PATH") or os.path.join(_HERE, "libgpcore.so")   # GPCORE_LIB_PATH: lab builds (tools/lab)
 
 GP_OK, GP_EINVAL, GP_ENOTPD, GP_ENOMEM, GP_EHIP, GP_ERANGE, GP_ERCCL, GP_EPEER = range(8)
 GP_DIST_ID_BYTES = 128

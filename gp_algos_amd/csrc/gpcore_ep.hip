@@ -99,9 +99,12 @@ __device__ __forceinline__ void ep_chunk_tile(double *A, const double *cs, int L
 
 #ifdef EP_STAMPS   // lab instrumentation (tools/ep_block_stamps.py): cycle stamps of one block's site iterations; never defined in the library build
 __device__ unsigned long long ep_stamps[4 * GP_NB];
+// phase stamps of ep_block2_kernel (tools/ep_block2_stamps.py): slot 2k = s_memrealtime (100 MHz), 2k + 1 = s_memtime (shader clock)
+#define EP2_STAMP(k) do { if (i0 == 5 * GP_NB && tid == 0 && blockIdx.x == 0) { ep_stamps[2 * (k)] = __builtin_amdgcn_s_memrealtime(); ep_stamps[2 * (k) + 1] = __builtin_amdgcn_s_memtime(); } } while (0)
 #define EP_STAMP(slot) do { if (i0 == 5 * GP_NB) ep_stamps[(slot)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define EP_STAMP(slot) do { } while (0)
+#define EP2_STAMP(k) do { } while (0)
 #endif
 
 // All site updates of one block of <= 128 consecutive sites (EpParameterEstimator.scala:44-55), on chip, by ONE
@@ -377,9 +380,13 @@ struct ep_site_regs {
     double to_n, no_n, yi_n;   // site parameters of the site about to be processed, fetched one site ahead
 };
 
-template <int P, bool HI, bool FULL>
+// (o0, o1): LDS row offsets of the lane's two rows.  Sites 0..63 of a block live in rows lane (register set 0), sites 64..127 in rows
+// lane + 64: at the block's half-way point the caller SWAPS the two register sets (and passes o0 = 64, o1 = 0), so that the row of the
+// site being processed is always in set 0 and ONE instantiation serves both halves -- two made 60 KB of code per kernel, and the
+// first chunk of the second half paid an instruction-cache miss of ~4 us (profiles/r03_i_block2_stamps.txt)
+template <int P, bool FULL>
 __device__ __forceinline__ void ep_site_steps(ep_site_regs &st, double *A, double *cs, double *cf, double *ob, const double *tb,
-                                              const double *nb, const double *yb, int cs0, int bsz, int lane) {
+                                              const double *nb, const double *yb, int cs0, int bsz, int lane, int o0, int o1) {
     constexpr int LS = GP_NB + 1;
     if constexpr (P < 16) {
         const int t = cs0 + P;
@@ -388,9 +395,9 @@ __device__ __forceinline__ void ep_site_steps(ep_site_regs &st, double *A, doubl
             // What the chain needs from row t, as lane broadcasts of values that were final BEFORE site t-1's result: its column entry
             // without site t-1's term (Pv), S[t, t-1] (Bv) and its mean without site t-1's update (Mv) -- two operations then
             // separate (c, coef) of site t-1 from the start of this chain: s_ii = Pv - c Bv^2, mu_i = Mv + Bv coef.
-            const double Pv = rl64(HI ? st.p1 : st.p0, own);
-            const double Bv = rl64(HI ? st.sp1 : st.sp0, own);          // (first site of the block: sp = 0)
-            const double Mv = rl64(HI ? st.m1 : st.m0, own);
+            const double Pv = rl64(st.p0, own);
+            const double Bv = rl64(st.sp0, own);          // (first site of the block: sp = 0)
+            const double Mv = rl64(st.m0, own);
             const double sii = (P > 0) ? fma(-(st.c_prev * Bv), Bv, Pv) : Pv;    // chunk start: the boundary tiles applied site t-1 already
             const double mui = fma(Bv, st.coef_prev, Mv);
             // column t becomes final for every row (the term of site t-1 was the only one missing), the mean takes site t-1's update
@@ -403,8 +410,8 @@ __device__ __forceinline__ void ep_site_steps(ep_site_regs &st, double *A, doubl
             st.m0 = fma(st.sp0, st.coef_prev, st.m0);      // (site 0 of the block: sp = coef_prev = 0)
             st.m1 = fma(st.sp1, st.coef_prev, st.m1);
             st.S0[P] = s0, st.S1[P] = s1, st.sp0 = s0, st.sp1 = s1;
-            A[lane + t * LS] = s0;
-            A[lane + 64 + t * LS] = s1;
+            A[lane + o0 + t * LS] = s0;
+            A[lane + o1 + t * LS] = s1;
             const double to = st.to_n, no = st.no_n, yi = st.yi_n;
             // column t+1 without the term of site t: independent of the chain below
             if constexpr (P < 15) {
@@ -413,11 +420,11 @@ __device__ __forceinline__ void ep_site_steps(ep_site_regs &st, double *A, doubl
                     double q0 = st.a0, q1 = st.a1;
                     // (LDS reads one site ahead of their use: column t+2, parameters of site t+1; clamped inside the arrays)
                     const int t2 = (P < 14 && t + 2 < GP_NB) ? t + 2 : t + 1;
-                    st.a0 = A[lane + t2 * LS], st.a1 = A[lane + 64 + t2 * LS];
+                    st.a0 = A[lane + o0 + t2 * LS], st.a1 = A[lane + o1 + t2 * LS];
                     st.to_n = tb[t + 1], st.no_n = nb[t + 1], st.yi_n = yb[t + 1];
 #pragma unroll
                     for (int q = 0; q < P; ++q) {
-                        const double wq = st.cq[q] * rl64(HI ? st.S1[q] : st.S0[q], own1);
+                        const double wq = st.cq[q] * rl64(st.S0[q], own1);
                         q0 = fma(-wq, st.S0[q], q0);
                         q1 = fma(-wq, st.S1[q], q1);
                     }
@@ -431,6 +438,9 @@ __device__ __forceinline__ void ep_site_steps(ep_site_regs &st, double *A, doubl
             const double cm = nc * cvr;
             const double rt = rsqrt(1.0 + cvr);
             const double z = (yi * cm) * rt;
+            // (a hand-written erf / exp pair -- Cody's rational approximations by Estrin's scheme, one exponential for both functions,
+            // scalar range branches -- was measured here: 1690 cycles per site against 1370 with the device library's, and four
+            // times the code; profiles/r03_i_block2_stamps.txt)
             const double Phi = 0.5 * (1.0 + erf(z * 0.70710678118654752440));
             const double ratio = dnorm_d(z) * rcp_nr(Phi);
             const double mi_hat = cm + (yi * cvr) * (ratio * rt);
@@ -444,7 +454,7 @@ __device__ __forceinline__ void ep_site_steps(ep_site_regs &st, double *A, doubl
             double *o = ob + 5 * t;
             o[0] = rs, o[1] = to, o[2] = sg_hat, o[3] = mi_hat, o[4] = nc;
         }
-        ep_site_steps<P + 1, HI, FULL>(st, A, cs, cf, ob, tb, nb, yb, cs0, bsz, lane);
+        ep_site_steps<P + 1, FULL>(st, A, cs, cf, ob, tb, nb, yb, cs0, bsz, lane, o0, o1);
     }
 }
 
@@ -500,19 +510,19 @@ __global__ __launch_bounds__(64 * EP_BLOCK1_WAVES) void ep_block1_kernel(int n, 
     for (int ch = 0; ch < jtiles; ++ch) {
         const int cs0 = 16 * ch;
         if (wave == 0) {
-            st.p0 = A[lane + cs0 * LS];          // the chunk's first column is final as it stands (the boundary tiles applied every earlier site)
-            st.p1 = A[lane + 64 + cs0 * LS];
-            const int c1 = cs0 + 1 < GP_NB ? cs0 + 1 : cs0;
-            st.a0 = A[lane + c1 * LS], st.a1 = A[lane + 64 + c1 * LS];
-            st.to_n = tb[cs0], st.no_n = nb[cs0], st.yi_n = yb[cs0];
-            const bool full = cs0 + 16 <= bsz;
-            if (cs0 < 64) {
-                if (full) ep_site_steps<0, false, true>(st, A, cs, cf, ob, tb, nb, yb, cs0, bsz, lane);
-                else ep_site_steps<0, false, false>(st, A, cs, cf, ob, tb, nb, yb, cs0, bsz, lane);
-            } else {
-                if (full) ep_site_steps<0, true, true>(st, A, cs, cf, ob, tb, nb, yb, cs0, bsz, lane);
-                else ep_site_steps<0, true, false>(st, A, cs, cf, ob, tb, nb, yb, cs0, bsz, lane);
+            if (cs0 == 64) {                     // second half of the block: the site rows are the lanes' second rows from here on
+                double t_;
+                t_ = st.m0, st.m0 = st.m1, st.m1 = t_;
+                t_ = st.sp0, st.sp0 = st.sp1, st.sp1 = t_;
             }
+            const int o0 = cs0 < 64 ? 0 : 64, o1 = 64 - o0;
+            st.p0 = A[lane + o0 + cs0 * LS];     // the chunk's first column is final as it stands (the boundary tiles applied every earlier site)
+            st.p1 = A[lane + o1 + cs0 * LS];
+            const int c1 = cs0 + 1 < GP_NB ? cs0 + 1 : cs0;
+            st.a0 = A[lane + o0 + c1 * LS], st.a1 = A[lane + o1 + c1 * LS];
+            st.to_n = tb[cs0], st.no_n = nb[cs0], st.yi_n = yb[cs0];
+            if (cs0 + 16 <= bsz) ep_site_steps<0, true>(st, A, cs, cf, ob, tb, nb, yb, cs0, bsz, lane, o0, o1);
+            else ep_site_steps<0, false>(st, A, cs, cf, ob, tb, nb, yb, cs0, bsz, lane, o0, o1);
         } else if (ch > 0) {
             // the chunk closed at the last boundary, applied to the tile columns right of the current chunk's: J = ch+1 .. jtiles-1, I = J .. 7
             int k = wave - 1;
@@ -574,22 +584,63 @@ __global__ __launch_bounds__(64 * EP_BLOCK1_WAVES) void ep_block1_kernel(int n, 
 // stream's consumer is preceded by ep_wait_flag_kernel, so it starts ~25 us into this kernel instead of after its ~100 us.
 // blockIdx.x = problem of a lockstep batch (ep_strides; a single run has one).
 struct ep_strides {
-    size_t sig = 0, vec = 0, y = 0, blk = 0, cvec = 0;   // in elements, per problem
+    size_t sig = 0, vec = 0, y = 0, blk = 0, cvec = 0, sc = 0;   // in elements, per problem
     int flag = 0;
 };
 constexpr int EP2_XS = 144;   // LDS column stride of the prologue's 128-row strip: 1152 B = 128 (mod 256) -> conflict-free fragments
 constexpr int EP_BLOCK2_LDS = (GP_NB * EP2_XS + 8 * GP_NB + 5 * GP_NB + 16) * (int)sizeof(double);   // 160 896 B of the CU's 163 840
 constexpr int EP_BLK_ELEMS = GP_NB * GP_NB + 8 * 256;   // Lmat + its tile inverses
 
+// Everything of chunk j (sites 16 j .. 16 j + 15) that other kernels read, written by the three helper waves while wave 0 runs
+// the next chunk: the chunk's columns of the unit-lower factor Lmat = I + strict_lower(S diag(c)) (final as soon as its sites are:
+// column q of S is complete for every row of the block once site q has been processed), the inverse of its 16 x 16 diagonal tile,
+// and the reference's outputs for its sites (:45-51 as written).  After the last chunk only that chunk's share is left -- the
+// all-at-the-end form was 9.4 us of every block's ~137 (profiles/r03_i_block2_stamps.txt).
+__device__ __forceinline__ void ep_chunk_outputs(int j, int bsz, int i0, const double *A, const double *cs, const double *ob, double *tau,
+                                                 double *nu, double *cav_tau, double *cav_nu, double *Lmat, double *Ldinv, int hid, int nh,
+                                                 int fr, bool inv_wave) {
+    constexpr int LS = GP_NB + 1;
+    const int c0 = 16 * j;
+    for (int e = hid; e < 16 * GP_NB; e += nh) {
+        const int r = e & (GP_NB - 1), c = c0 + (e >> 7);
+        Lmat[r + (size_t)c * GP_NB] = (r == c) ? 1.0 : ((r > c && c < bsz) ? A[r + c * LS] * cs[c] : 0.0);
+    }
+    if (hid < 16 && c0 + hid < bsz) {
+        const int r = c0 + hid;
+        const double *o = ob + 5 * r;
+        const double tc = o[0] - o[1];                              // cavity tau  :45
+        const double isg = rcp_nr(o[2]);
+        const double dtau = isg - tc - o[1];                        // :49
+        tau[i0 + r] = o[1] + dtau;                                  // :50
+        nu[i0 + r] = o[3] * isg - o[4];                             // :51
+        cav_tau[i0 + r] = tc;
+        cav_nu[i0 + r] = o[4];
+    }
+    if (inv_wave) {   // one wave: the tile in each of its four 16-lane rows (DPP row broadcasts, dpp_tile.h); the first row stores
+        double row[16], sv[16], x[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            row[k] = (c0 + k < bsz) ? A[(c0 + fr) + (c0 + k) * LS] * cs[c0 + k] : 0.0;
+            sv[k] = (k == fr) ? 1.0 : 0.0;
+        }
+        tile_unit_inverse<0>(row, sv, x);
+        if ((hid & 63) < 16) {
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) Ldinv[j * 256 + rr + 16 * fr] = x[rr];
+        }
+    }
+}
+
 template <bool PRO>
 __global__ __launch_bounds__(64 * EP_BLOCK1_WAVES) void ep_block2_kernel(int n, int np, int i0, int bsz, double *__restrict__ Sig,
                                                                         double *__restrict__ vec, const int *__restrict__ y,
                                                                         double *__restrict__ blk, double *__restrict__ cvbase,
-                                                                        int *__restrict__ flags, int par, int token, ep_strides es) {
+                                                                        double *__restrict__ Scbase, int *__restrict__ flags, int par,
+                                                                        int token, ep_strides es) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     constexpr int LS = GP_NB + 1;
     Sig += (size_t)blockIdx.x * es.sig, vec += (size_t)blockIdx.x * es.vec, y += (size_t)blockIdx.x * es.y;
-    blk += (size_t)blockIdx.x * es.blk, cvbase += (size_t)blockIdx.x * es.cvec;
+    blk += (size_t)blockIdx.x * es.blk, cvbase += (size_t)blockIdx.x * es.cvec, Scbase += (size_t)blockIdx.x * es.sc;
     flags += (size_t)blockIdx.x * es.flag;
     double *tau = vec, *nu = vec + np, *cav_tau = vec + 5 * (size_t)np, *cav_nu = vec + 6 * (size_t)np;
     const double *mu = vec + 4 * (size_t)np;
@@ -603,9 +654,12 @@ __global__ __launch_bounds__(64 * EP_BLOCK1_WAVES) void ep_block2_kernel(int n, 
     double *tb = mb + GP_NB;                 // site parameters and labels, staged once
     double *nb = tb + GP_NB;
     double *yb = nb + GP_NB;
-    double *ob = yb + 3 * GP_NB;             // [site][5]: 1/sii, tau_old, sg, mi, cavity nu
+    double *pcs = yb + GP_NB;                // prologue: c and coef of the block before
+    double *pcf = pcs + GP_NB;
+    double *ob = pcf + GP_NB;                // [site][5]: 1/sii, tau_old, sg, mi, cavity nu
     const int tid = threadIdx.x, r = tid, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
     const bool rowthread = tid < GP_NB;
+    EP2_STAMP(0);
     if (rowthread) {
         cs[r] = 0.0;
         cf[r] = 0.0;
@@ -616,14 +670,16 @@ __global__ __launch_bounds__(64 * EP_BLOCK1_WAVES) void ep_block2_kernel(int n, 
     }
     if constexpr (PRO) {
         const double *pL = blk + (size_t)(1 - par) * EP_BLK_ELEMS, *pdinv = pL + GP_NB * GP_NB;     // the block before: unit-lower factor,
-        const double *pc = cvbase + (size_t)(1 - par) * 2 * GP_NB, *pcoef = pc + GP_NB;             //   its tile inverses, c and coef
+        const double *pc = cvbase + (size_t)(1 - par) * 2 * GP_NB;                                  //   its tile inverses, c and coef
         double *X = Sig + i0 + (size_t)(i0 - GP_NB) * np;      // rows of this block, columns of the block before (solved in place)
+        double *X2 = Scbase + i0;                              // X diag(c), leading dimension np
         const double *D = Sig + i0 + (size_t)i0 * np;
         {   // strip by LDS-DMA: one wave instruction = one 128-row column (1 KiB), 32 per wave, all in flight
             const double *src = X + lane * 2 + (size_t)wave * np;
 #pragma unroll
             for (int q = 0; q < GP_NB / 4; ++q) __builtin_amdgcn_global_load_lds(src + (size_t)(4 * q) * np, xs + (wave + 4 * q) * EP2_XS, 16, 0, 0);
         }
+        if (rowthread) pcs[r] = pc[r], pcf[r] = pc[GP_NB + r];
         // this wave's nine lower tiles of D (q = wave, wave + 4, ...): fetched under the solve
         double4_t dacc[9];
 #pragma unroll
@@ -633,78 +689,142 @@ __global__ __launch_bounds__(64 * EP_BLOCK1_WAVES) void ep_block2_kernel(int n, 
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) dacc[u][rr] = D[(16 * I + fr) + (size_t)(16 * J + fg + 4 * rr) * np];
         }
-        double fa[28], fb[28];
-        trsm_load_frags<1>(pL, GP_NB, fr, fg, fa);
+        // ALL fragments of the unit-lower factor and of its tile inverses up front (112 + 32 doubles per lane): the factor was
+        // written by the kernel before on another CU, so each fetch is an L2 miss served over the fabric; fetched one chunk ahead,
+        // as the stand-alone link kernel does, those latencies sat between the eight short chunk steps
+        double f1[28], f2[28], f3[28], f4[28], f5[28], f6[28], f7[28], dq[8][4];
+        trsm_load_frags<1>(pL, GP_NB, fr, fg, f1);
+        trsm_load_frags<2>(pL, GP_NB, fr, fg, f2);
+        trsm_load_frags<3>(pL, GP_NB, fr, fg, f3);
+        trsm_load_frags<4>(pL, GP_NB, fr, fg, f4);
+        trsm_load_frags<5>(pL, GP_NB, fr, fg, f5);
+        trsm_load_frags<6>(pL, GP_NB, fr, fg, f6);
+        trsm_load_frags<7>(pL, GP_NB, fr, fg, f7);
+#pragma unroll
+        for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) dq[cb][rr] = pdinv[cb * 256 + fr + 16 * (fg + 4 * rr)];
         __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the DMA has landed (and the loads above)
         __syncthreads();
+        EP2_STAMP(1);
         // X <- X Lmat^-T: rows are independent, every wave solves its own 32 (two 16-row sub-strips share the L fragments)
         const int sp0 = wave * 32 + fr, sp1 = sp0 + 16;
-        double ss = 0.0;
-#define EP2_CHUNK(CB, F) do { trsm_chunk<CB, EP2_XS>(xs, sp0, fr, fg, F, pdinv, ss); trsm_chunk<CB, EP2_XS>(xs, sp1, fr, fg, F, pdinv, ss); } while (0)
-        trsm_load_frags<2>(pL, GP_NB, fr, fg, fb);
-        EP2_CHUNK(0, fa);
-        EP2_CHUNK(1, fa);
-        trsm_load_frags<3>(pL, GP_NB, fr, fg, fa);
-        EP2_CHUNK(2, fb);
-        trsm_load_frags<4>(pL, GP_NB, fr, fg, fb);
-        EP2_CHUNK(3, fa);
-        trsm_load_frags<5>(pL, GP_NB, fr, fg, fa);
-        EP2_CHUNK(4, fb);
-        trsm_load_frags<6>(pL, GP_NB, fr, fg, fb);
-        EP2_CHUNK(5, fa);
-        trsm_load_frags<7>(pL, GP_NB, fr, fg, fa);
-        EP2_CHUNK(6, fb);
-        EP2_CHUNK(7, fa);
+#define EP2_CHUNK(CB, F) trsm_chunk_pre2<CB, EP2_XS>(xs, sp0, sp1, fr, fg, F, dq[CB])
+        EP2_CHUNK(0, f1);
+        EP2_CHUNK(1, f1);
+        EP2_CHUNK(2, f2);
+        EP2_CHUNK(3, f3);
+        EP2_CHUNK(4, f4);
+        EP2_CHUNK(5, f5);
+        EP2_CHUNK(6, f6);
+        EP2_CHUNK(7, f7);
 #undef EP2_CHUNK
-        (void)ss;
+        EP2_STAMP(2);
         __syncthreads();
-        {   // the solved rows go out now (the side stream's column-panel update multiplies by them; their scaled copy is only ever
-            // used by the tile update below, which scales on the fly): the stores drain while the matrix cores run that update
+        EP2_STAMP(3);
+        {   // the solved rows and their scaled copy go out now (operands of the side stream's trailing update, which covers this
+            // block's column panel too): the stores drain while the matrix cores run the tile update
             const int li = lane * 2, lc = wave;
 #pragma unroll 8
             for (int q = 0; q < GP_NB / 4; ++q) {
                 const int c = lc + 4 * q;
-                *reinterpret_cast<double2_t *>(X + li + (size_t)c * np) = *reinterpret_cast<const double2_t *>(xs + c * EP2_XS + li);
+                double2_t v = *reinterpret_cast<const double2_t *>(xs + c * EP2_XS + li);
+                *reinterpret_cast<double2_t *>(X + li + (size_t)c * np) = v;
+                const double sc = pcs[c];
+                v.x *= sc, v.y *= sc;
+                *reinterpret_cast<double2_t *>(X2 + li + (size_t)c * np) = v;
             }
         }
         if (rowthread) {   // mean of this block's rows: + X coef of the block before (the O(n) form of mu = Sigma nu, Appendix A.3)
-            double acc = 0.0;
-#pragma unroll 8
-            for (int c = 0; c < GP_NB; ++c) acc = fma(xs[c * EP2_XS + r], pcoef[c], acc);
+            double acc = 0.0;      // (one accumulator, columns ascending: the link kernel's order, bit for bit)
+#pragma unroll 16
+            for (int c = 0; c < GP_NB; ++c) acc = fma(xs[c * EP2_XS + r], pcf[c], acc);
             mb[r] = ((i0 + r < n) ? mu[i0 + r] : 0.0) + acc;
         }
-        // D(lower) -= X diag(c) X^T: nine tiles per wave, K = 128, operands from the strip
+        EP2_STAMP(4);
+        {   // D(lower) -= X diag(c) X^T: nine tiles per wave, K = 128, operands from the strip; c of this lane's k values once
+            double ck[32];
 #pragma unroll
-        for (int u = 0; u < 9; ++u) {
-            int I, J;
-            tri_coords(wave + 4 * u, I, J);
-            double4_t acc = dacc[u];
-#pragma unroll 8
-            for (int ks = 0; ks < 32; ++ks) {
-                const int k = 4 * ks + fg;
-                const double aop = -(pc[k] * xs[k * EP2_XS + 16 * J + fr]);
-                const double bop = xs[k * EP2_XS + 16 * I + fr];
-                acc = MFMA(aop, bop, acc);
+            for (int ks = 0; ks < 32; ++ks) ck[ks] = -pcs[4 * ks + fg];
+            // Tiles in pairs (a triple at the end): independent accumulator chains, and the LDS operands of the next two k steps
+            // requested before the MFMAs of the current two are issued (explicit double buffering between sched_barriers; the
+            // compiler's own order -- read, wait out the LDS latency, multiply -- ran at 112 cycles per 64-cycle MFMA).  Every
+            // tile's sum stays in k order: the same bits as the stand-alone link kernel.
+#define EP2_LD(buf, T, ks) do { const int k_ = 4 * (ks) + fg; \
+            _Pragma("unroll") for (int t_ = 0; t_ < T; ++t_) { buf[2 * t_] = xs[k_ * EP2_XS + 16 * Jt[t_] + fr]; buf[2 * t_ + 1] = xs[k_ * EP2_XS + 16 * It[t_] + fr]; } } while (0)
+#pragma unroll
+            for (int u = 0; u < 6; u += 2) {
+                int It[2], Jt[2];
+                tri_coords(wave + 4 * u, It[0], Jt[0]);
+                tri_coords(wave + 4 * (u + 1), It[1], Jt[1]);
+                double4_t acc0 = dacc[u], acc1 = dacc[u + 1];
+                double c0[4], c1[4], n0[4], n1[4];
+                EP2_LD(c0, 2, 0);
+                EP2_LD(c1, 2, 1);
+#pragma unroll
+                for (int ks = 0; ks < 32; ks += 2) {
+                    if (ks + 2 < 32) { EP2_LD(n0, 2, ks + 2); EP2_LD(n1, 2, ks + 3); }
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc0 = MFMA(ck[ks] * c0[0], c0[1], acc0);
+                    acc1 = MFMA(ck[ks] * c0[2], c0[3], acc1);
+                    acc0 = MFMA(ck[ks + 1] * c1[0], c1[1], acc0);
+                    acc1 = MFMA(ck[ks + 1] * c1[2], c1[3], acc1);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) c0[i] = n0[i], c1[i] = n1[i];
+                }
+                dacc[u] = acc0, dacc[u + 1] = acc1;
+                if (u == 0) {
+                    // The solved rows have had a tile pair's worth of time (~3 us) to drain: announce them now rather than after
+                    // the whole update -- the side stream's trailing update of the block before starts ~10 us earlier, and it is
+                    // as much on the sweep's critical path as this kernel (profiles/r03_e_sweep_fused.txt)
+                    __builtin_amdgcn_s_waitcnt(0x0F70);   // this wave's stores of X / X2 are acknowledged
+                    __syncthreads();
+                    if (tid == 64) {
+                        __threadfence();
+                        __hip_atomic_store(flags + i0 / GP_NB, token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
             }
-            dacc[u] = acc;
+            {
+                int It[3], Jt[3];
+                tri_coords(wave + 24, It[0], Jt[0]);
+                tri_coords(wave + 28, It[1], Jt[1]);
+                tri_coords(wave + 32, It[2], Jt[2]);
+                double4_t acc0 = dacc[6], acc1 = dacc[7], acc2 = dacc[8];
+                double c0[6], c1[6], n0[6], n1[6];
+                EP2_LD(c0, 3, 0);
+                EP2_LD(c1, 3, 1);
+#pragma unroll
+                for (int ks = 0; ks < 32; ks += 2) {
+                    if (ks + 2 < 32) { EP2_LD(n0, 3, ks + 2); EP2_LD(n1, 3, ks + 3); }
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc0 = MFMA(ck[ks] * c0[0], c0[1], acc0);
+                    acc1 = MFMA(ck[ks] * c0[2], c0[3], acc1);
+                    acc2 = MFMA(ck[ks] * c0[4], c0[5], acc2);
+                    acc0 = MFMA(ck[ks + 1] * c1[0], c1[1], acc0);
+                    acc1 = MFMA(ck[ks + 1] * c1[2], c1[3], acc1);
+                    acc2 = MFMA(ck[ks + 1] * c1[4], c1[5], acc2);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) c0[i] = n0[i], c1[i] = n1[i];
+                }
+                dacc[6] = acc0, dacc[7] = acc1, dacc[8] = acc2;
+            }
+#undef EP2_LD
         }
-        __builtin_amdgcn_s_waitcnt(0x0F70);   // this wave's stores of X / X2 are acknowledged
-        __syncthreads();                      // ... and nobody reads the strip any more
-        // the site loop's image of the block: lower tiles from the accumulators, the strictly upper tiles (never used) cleared
+        EP2_STAMP(5);
+        EP2_STAMP(6);
+        __syncthreads();                      // nobody reads the strip any more
+        EP2_STAMP(7);
+        // the site loop's image of the block: lower tiles from the accumulators.  (The strictly upper tiles keep whatever the strip
+        // left there: the site loop carries them through the lanes that own rows above the diagonal and never reads them back.)
 #pragma unroll
         for (int u = 0; u < 9; ++u) {
             int I, J;
             tri_coords(wave + 4 * u, I, J);
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) A[(16 * I + fr) + (16 * J + fg + 4 * rr) * LS] = dacc[u][rr];
-        }
-        for (int e = tid; e < GP_NB * GP_NB; e += 64 * EP_BLOCK1_WAVES) {
-            const int rr = e & (GP_NB - 1), cc = e >> 7;
-            if ((rr >> 4) < (cc >> 4)) A[rr + cc * LS] = 0.0;
-        }
-        if (tid == 64) {   // one lane announces X / X2 (every wave has waited for its stores before the barrier above)
-            __threadfence();
-            __hip_atomic_store(flags + i0 / GP_NB, token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
     } else {
         // first block of a sweep: the block of Sigma0 as it stands, every thread half of a row's columns, 16 loads in flight
@@ -720,7 +840,9 @@ __global__ __launch_bounds__(64 * EP_BLOCK1_WAVES) void ep_block2_kernel(int n, 
         if (rowthread) mb[r] = (i0 + r < n) ? mu[i0 + r] : 0.0;
     }
     __syncthreads();
+    EP2_STAMP(8);
     const int jtiles = (bsz + 15) >> 4;
+    const int hid = tid - 64;                // helper thread index (waves 1-3)
     ep_site_regs st;
     if (wave == 0) {
         st.m0 = mb[lane], st.m1 = mb[lane + 64];
@@ -729,62 +851,46 @@ __global__ __launch_bounds__(64 * EP_BLOCK1_WAVES) void ep_block2_kernel(int n, 
     for (int ch = 0; ch < jtiles; ++ch) {
         const int cs0 = 16 * ch;
         if (wave == 0) {
-            st.p0 = A[lane + cs0 * LS];          // the chunk's first column is final as it stands (the boundary tiles applied every earlier site)
-            st.p1 = A[lane + 64 + cs0 * LS];
-            const int c1 = cs0 + 1 < GP_NB ? cs0 + 1 : cs0;
-            st.a0 = A[lane + c1 * LS], st.a1 = A[lane + 64 + c1 * LS];
-            st.to_n = tb[cs0], st.no_n = nb[cs0], st.yi_n = yb[cs0];
-            const bool full = cs0 + 16 <= bsz;
-            if (cs0 < 64) {
-                if (full) ep_site_steps<0, false, true>(st, A, cs, cf, ob, tb, nb, yb, cs0, bsz, lane);
-                else ep_site_steps<0, false, false>(st, A, cs, cf, ob, tb, nb, yb, cs0, bsz, lane);
-            } else {
-                if (full) ep_site_steps<0, true, true>(st, A, cs, cf, ob, tb, nb, yb, cs0, bsz, lane);
-                else ep_site_steps<0, true, false>(st, A, cs, cf, ob, tb, nb, yb, cs0, bsz, lane);
+            if (cs0 == 64) {                     // second half of the block: the site rows are the lanes' second rows from here on
+                double t_;
+                t_ = st.m0, st.m0 = st.m1, st.m1 = t_;
+                t_ = st.sp0, st.sp0 = st.sp1, st.sp1 = t_;
             }
+            const int o0 = cs0 < 64 ? 0 : 64, o1 = 64 - o0;
+            st.p0 = A[lane + o0 + cs0 * LS];     // the chunk's first column is final as it stands (the boundary tiles applied every earlier site)
+            st.p1 = A[lane + o1 + cs0 * LS];
+            const int c1 = cs0 + 1 < GP_NB ? cs0 + 1 : cs0;
+            st.a0 = A[lane + o0 + c1 * LS], st.a1 = A[lane + o1 + c1 * LS];
+            st.to_n = tb[cs0], st.no_n = nb[cs0], st.yi_n = yb[cs0];
+            if (cs0 + 16 <= bsz) ep_site_steps<0, true>(st, A, cs, cf, ob, tb, nb, yb, cs0, bsz, lane, o0, o1);
+            else ep_site_steps<0, false>(st, A, cs, cf, ob, tb, nb, yb, cs0, bsz, lane, o0, o1);
+            EP2_STAMP(9 + ch);
         } else if (ch > 0) {
+            // the chunk closed at the last boundary, applied to the tile columns right of the current chunk's: J = ch+1 .. jtiles-1, I = J .. 7
             int k = wave - 1;
             for (int J = ch + 1; J < jtiles; ++J)
                 for (int I = J; I < 8; ++I, k = (k == 0 ? EP_BLOCK1_WAVES - 2 : k - 1))
                     if (k == 0) ep_chunk_tile(A, cs, LS, I, J, cs0 - 16, fr, fg);
+            // ... and everything other kernels read of that chunk
+            ep_chunk_outputs(ch - 1, bsz, i0, A, cs, ob, tau, nu, cav_tau, cav_nu, Lmat, Ldinv, hid, 64 * (EP_BLOCK1_WAVES - 1), fr, wave == 1);
         }
         __syncthreads();
         if (ch + 1 < jtiles) {
+            // the finished chunk applied to the next chunk's own tile column
             const int jc = ch + 1;
             for (int I = jc + wave; I < 8; I += EP_BLOCK1_WAVES) ep_chunk_tile(A, cs, LS, I, jc, cs0, fr, fg);
             __syncthreads();
         }
     }
-    // outputs of all sites (:45-51 as written), one thread per site
-    if (rowthread && r < bsz) {
-        const double *o = ob + 5 * r;
-        const double tc = o[0] - o[1];                              // cavity tau  :45
-        const double isg = rcp_nr(o[2]);
-        const double dtau = isg - tc - o[1];                        // :49
-        tau[i0 + r] = o[1] + dtau;                                  // :50
-        nu[i0 + r] = o[3] * isg - o[4];                             // :51
-        cav_tau[i0 + r] = tc;
-        cav_nu[i0 + r] = o[4];
-        cvec[r] = cs[r];
-        ncoef[r] = cf[r];
+    EP2_STAMP(17);
+    // what is left: the last chunk's share, the identity for sites a ragged block does not have, c and coef of every site
+    if (wave > 0) ep_chunk_outputs(jtiles - 1, bsz, i0, A, cs, ob, tau, nu, cav_tau, cav_nu, Lmat, Ldinv, hid, 64 * (EP_BLOCK1_WAVES - 1), fr, wave == 1);
+    else {
+        for (int j = jtiles; j < 8; ++j) ep_chunk_outputs(j, bsz, i0, A, cs, ob, tau, nu, cav_tau, cav_nu, Lmat, Ldinv, lane, 64, fr, true);
+        cvec[lane] = lane < bsz ? cs[lane] : 0.0, cvec[lane + 64] = lane + 64 < bsz ? cs[lane + 64] : 0.0;
+        ncoef[lane] = lane < bsz ? cf[lane] : 0.0, ncoef[lane + 64] = lane + 64 < bsz ? cf[lane + 64] : 0.0;
     }
-    if (rowthread) {
-        if (r >= bsz) { cvec[r] = 0.0; ncoef[r] = 0.0; }
-        for (int c = 0; c < GP_NB; ++c)
-            Lmat[r + (size_t)c * GP_NB] = (r == c) ? 1.0 : ((r > c && c < bsz) ? A[r + c * LS] * cs[c] : 0.0);
-    }
-    if (wave == 2 || wave == 3) {   // unit-lower tile inverses of Lmat, as in ep_block_kernel
-        const int c0 = 16 * (4 * (wave - 2) + fg);
-        double row[16], sv[16], x[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            row[k] = (c0 + k < bsz) ? A[(c0 + fr) + (c0 + k) * LS] * cs[c0 + k] : 0.0;
-            sv[k] = (k == fr) ? 1.0 : 0.0;
-        }
-        tile_unit_inverse<0>(row, sv, x);
-#pragma unroll
-        for (int rr = 0; rr < 16; ++rr) Ldinv[(c0 / 16) * 256 + rr + 16 * fr] = x[rr];
-    }
+    EP2_STAMP(18);
 }
 
 // One thread per problem waits for the flag ep_block2_kernel sets when the solved rows of block `b` are in memory.  The wait is
@@ -1231,10 +1337,10 @@ gp_status gp_ep_sweep(gp_ep *ep, int nsweeps, double *tau, double *nu, int *info
                 if (b >= 2) GP_HIP(ctx, hipStreamWaitEvent(s, ep->ev[4 * (b - 2) + 2], 0));
                 if (b > 0)
                     hipLaunchKernelGGL(ep_block2_kernel<true>, dim3(1), dim3(64 * EP_BLOCK1_WAVES), EP_BLOCK2_LDS, s, n, np, i0, bsz, ep->Sig, ep->vec,
-                                       ep->y, ep->blk, ep->cvec, ep->flags, par, token, ep_strides());
+                                       ep->y, ep->blk, ep->cvec, ep->Sc, ep->flags, par, token, ep_strides());
                 else
                     hipLaunchKernelGGL(ep_block2_kernel<false>, dim3(1), dim3(64 * EP_BLOCK1_WAVES), EP_BLOCK2_LDS, s, n, np, i0, bsz, ep->Sig, ep->vec,
-                                       ep->y, ep->blk, ep->cvec, ep->flags, par, token, ep_strides());
+                                       ep->y, ep->blk, ep->cvec, ep->Sc, ep->flags, par, token, ep_strides());
             } else if (block1)
                 hipLaunchKernelGGL(ep_block1_kernel, dim3(1), dim3(64 * EP_BLOCK1_WAVES), EP_BLOCK1_LDS, s, n, np, i0, bsz, ep->Sig, ep->mu(), ep->y,
                                    ep->tau(), ep->nu(), ep->cav_tau(), ep->cav_nu(), cvec, ncoef, Lmat, bdinv);
@@ -1265,14 +1371,21 @@ gp_status gp_ep_sweep(gp_ep *ep, int nsweeps, double *tau, double *nu, int *info
                 }
             }
             if (fused && b > 0) {
-                // side stream, part 2 of block b-1: the column panel of block b below its diagonal tile.  It needs the rows this
-                // kernel's prologue has just solved: announced by a device flag, awaited by a one-thread kernel (enqueued AFTER the
-                // producer, which depends on nothing later on any stream; the wait is bounded and reports instead of hanging)
-                const int prest = np - i0 - GP_NB;           // rows from block b+1 on
-                if (prest > 0) {
+                // side stream: block b-1's whole trailing update, Sigma[i0:, i0:] -= Sc S^T (lower), in ONE launch.  Its operands' first
+                // 128 rows are what this kernel's prologue has just solved: announced by a device flag, awaited by a one-thread kernel
+                // (enqueued AFTER the producer, which depends on nothing later on any stream; the wait is bounded and reports instead
+                // of hanging).  The rows below were solved by the side stream itself in the iteration before.  (The tile of this
+                // block itself, which the chain keeps in LDS, is updated here too -- nobody reads it again -- so that the product is
+                // one lower-trapezoid launch.)  Every launch on this stream costs ~40 us while the other streams' GEMMs hold the CUs,
+                // whatever its size (profiles/r03_d_sweep_urgent_first.txt), so the chain's slack is spent on three launches per block
+                // (solve, wait, update), not on five.
+                const int prt = np - i0;
+                if (prt > GP_NB) {
                     hipLaunchKernelGGL(ep_wait_flag_kernel, dim3(1), dim3(1), 0, s2, ep->flags + b, 0, token, flag_err);
-                    const double *pSt = ep->Sig + (size_t)i0 + (size_t)(i0 - GP_NB) * np, *pSct = ep->Sc + i0;
-                    gpk_gemm_nt(s2, prest, GP_NB, GP_NB, -1.0, pSct + GP_NB, np, pSt, np, 1.0, ep->Sig + (size_t)(i0 + GP_NB) + (size_t)i0 * np, np, 0);
+                    gp_prof_begin(ctx, GP_PROF_GEMM, s2);
+                    gpk_gemm_nt(s2, prt, prt, GP_NB, -1.0, ep->Sc + i0, np, ep->Sig + (size_t)i0 + (size_t)(i0 - GP_NB) * np, np, 1.0,
+                                ep->Sig + (size_t)i0 + (size_t)i0 * np, np, 1);
+                    gp_prof_end(ctx, GP_PROF_GEMM, (double)prt * ((double)prt + GP_NB) * GP_NB, s2);
                 }
                 GP_HIP(ctx, hipEventRecord(ep->ev[4 * (b - 1) + 2], s2));
                 last_side = ep->ev[4 * (b - 1) + 2];
@@ -1293,9 +1406,11 @@ gp_status gp_ep_sweep(gp_ep *ep, int nsweeps, double *tau, double *nu, int *info
                 GP_HIP(ctx, hipStreamWaitEvent(s2, ev_fac, 0));
                 // side stream, part 1: rows [r0+128, np) of the panel solve and their own lower triangle of the update
                 gpk_trsm_panel128(s2, St + GP_NB, rest, np, Lmat, GP_NB, bdinv, nullptr, ncoef, ep->mu() + r0 + GP_NB, gp_batch(), Sct + GP_NB, cvec);
-                gp_prof_begin(ctx, GP_PROF_GEMM, s2);
-                gpk_gemm_nt(s2, rest, rest, GP_NB, -1.0, Sct + GP_NB, np, St + GP_NB, np, 1.0, Ctr + GP_NB + (size_t)GP_NB * np, np, 1);
-                gp_prof_end(ctx, GP_PROF_GEMM, (double)rest * ((double)rest + GP_NB) * GP_NB, s2);
+                if (!fused) {
+                    gp_prof_begin(ctx, GP_PROF_GEMM, s2);
+                    gpk_gemm_nt(s2, rest, rest, GP_NB, -1.0, Sct + GP_NB, np, St + GP_NB, np, 1.0, Ctr + GP_NB + (size_t)GP_NB * np, np, 1);
+                    gp_prof_end(ctx, GP_PROF_GEMM, (double)rest * ((double)rest + GP_NB) * GP_NB, s2);
+                }
             }
             if (fused) continue;     // the link is the next block kernel's prologue, part 2 follows its flag (above)
             // main stream: the 128 rows of block b+1 -- they read Sigma entries the side stream's update of block b-1 wrote
