@@ -408,23 +408,29 @@ void gpi_chol_blocked(gp_ctx *ctx, double *A, int np, int lda, double *dinv, int
 // and leaves everything to the right of it to `far`, which starts at `solved` and records `far_done`; the closing step of the next
 // outer panel waits for that event before it touches those columns (the look-ahead of chol_blocked, one step at a time).
 void gpi_chol_panel_step(gp_ctx *ctx, hipStream_t s, double *A, int np, int lda, double *dinv, int extra, int k0, hipEvent_t solved,
-                         hipStream_t far, hipEvent_t far_done) {
+                         hipStream_t far, hipEvent_t far_done, int count, size_t strideA, size_t strideDinv, int *info) {
     const int rows = np + extra;
     const int K0 = k0 / GP_OUTER * GP_OUTER, wcols = std::min(GP_OUTER, np - K0);
     double *Akk = A + (size_t)k0 + (size_t)k0 * lda;
     double *dk = dinv + (size_t)k0 * 16;
-    gpk_potrf_diag128(s, Akk, lda, dk, ctx->d_info, k0, gp_batch());
+    gp_batch bdiag, btrsm, bgemm;
+    bdiag.count = btrsm.count = bgemm.count = count;
+    bdiag.s0 = strideA, bdiag.s1 = strideDinv;
+    btrsm.s0 = strideA, btrsm.s1 = strideA, btrsm.s2 = strideDinv;
+    bgemm.s0 = bgemm.s1 = bgemm.s2 = strideA;
+    const bool single = count == 1;      // the quarter-tile kernel serves single problems; a batch fills the chip with 128 x 128 tiles
+    gpk_potrf_diag128(s, Akk, lda, dk, info ? info : ctx->d_info, k0, bdiag);
     const int r = rows - (k0 + GP_NB);
     double *A21 = Akk + GP_NB;
-    if (r > 0) gpk_trsm_panel128(s, A21, r, lda, Akk, lda, dk, nullptr, nullptr, nullptr, gp_batch());
+    if (r > 0) gpk_trsm_panel128(s, A21, r, lda, Akk, lda, dk, nullptr, nullptr, nullptr, btrsm);
     if (solved) (void)hipEventRecord(solved, s);
     if (r <= 0) return;
     const int c1 = K0 + wcols, wc = c1 - (k0 + GP_NB);
     if (wc > 0) {
         gp_prof_begin(ctx, GP_PROF_PANEL_UPD, s);
-        if (small_panel_update()) gpk_gemm_k128_sub(s, r, wc, A21, lda, A21, lda, A21 + (size_t)GP_NB * lda, lda, 1);
-        else gpk_gemm_nt(s, r, wc, GP_NB, -1.0, A21, lda, A21, lda, 1.0, A21 + (size_t)GP_NB * lda, lda, 1);
-        gp_prof_end(ctx, GP_PROF_PANEL_UPD, trapezoid_flops(r, wc, GP_NB), s);
+        if (single && small_panel_update()) gpk_gemm_k128_sub(s, r, wc, A21, lda, A21, lda, A21 + (size_t)GP_NB * lda, lda, 1);
+        else gpk_gemm_nt(s, r, wc, GP_NB, -1.0, A21, lda, A21, lda, 1.0, A21 + (size_t)GP_NB * lda, lda, 1, 0, bgemm);
+        gp_prof_end(ctx, GP_PROF_PANEL_UPD, count * trapezoid_flops(r, wc, GP_NB), s);
         return;
     }
     const int R = np - c1;
@@ -438,21 +444,21 @@ void gpi_chol_panel_step(gp_ctx *ctx, hipStream_t s, double *A, int np, int lda,
         const double *P2 = A + (size_t)c2 + (size_t)K0 * lda;
         const double tiles = trapezoid_flops(rows - c2, np - c2, wcols) / (2.0 * GP_NB * GP_NB * wcols);
         gp_prof_begin(ctx, GP_PROF_SYRK, far);
-        if (tiles < small_update_tiles() && small_panel_update())
+        if (single && tiles < small_update_tiles() && small_panel_update())
             gpk_gemm_k128_sub(far, rows - c2, np - c2, P2, lda, P2, lda, A + (size_t)c2 + (size_t)c2 * lda, lda, 1, wcols);
         else
-            gpk_gemm_nt(far, rows - c2, np - c2, wcols, -1.0, P2, lda, P2, lda, 1.0, A + (size_t)c2 + (size_t)c2 * lda, lda, 1);
-        gp_prof_end(ctx, GP_PROF_SYRK, trapezoid_flops(rows - c2, np - c2, wcols), far);
+            gpk_gemm_nt(far, rows - c2, np - c2, wcols, -1.0, P2, lda, P2, lda, 1.0, A + (size_t)c2 + (size_t)c2 * lda, lda, 1, 0, bgemm);
+        gp_prof_end(ctx, GP_PROF_SYRK, count * trapezoid_flops(rows - c2, np - c2, wcols), far);
     }
     if (split) (void)hipEventRecord(far_done, far);
     const double *P = A + (size_t)c1 + (size_t)K0 * lda;
     const double tiles128 = trapezoid_flops(rows - c1, near, wcols) / (2.0 * GP_NB * GP_NB * wcols);
     gp_prof_begin(ctx, GP_PROF_SYRK, s);
-    if (tiles128 < small_update_tiles() && small_panel_update())
+    if (single && tiles128 < small_update_tiles() && small_panel_update())
         gpk_gemm_k128_sub(s, rows - c1, near, P, lda, P, lda, A + (size_t)c1 + (size_t)c1 * lda, lda, 1, wcols);
     else
-        gpk_gemm_nt(s, rows - c1, near, wcols, -1.0, P, lda, P, lda, 1.0, A + (size_t)c1 + (size_t)c1 * lda, lda, 1);
-    gp_prof_end(ctx, GP_PROF_SYRK, trapezoid_flops(rows - c1, near, wcols), s);
+        gpk_gemm_nt(s, rows - c1, near, wcols, -1.0, P, lda, P, lda, 1.0, A + (size_t)c1 + (size_t)c1 * lda, lda, 1, 0, bgemm);
+    gp_prof_end(ctx, GP_PROF_SYRK, count * trapezoid_flops(rows - c1, near, wcols), s);
 }
 void gpi_solve_rows_lower(gp_ctx *ctx, double *Vt, int mp, const double *L, int np, int ldl, const double *dinv, double *sumsq,
                           const double *tvec, double *dots) { solve_rows_lower(ctx, Vt, mp, L, np, ldl, dinv, sumsq, tvec, dots); }

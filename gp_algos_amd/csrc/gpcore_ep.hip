@@ -23,6 +23,10 @@
 #include <thread>
 #include <vector>
 
+// Outer panel of the site loop's delayed updates (two-level, like the Cholesky): the columns up to one block past the current outer
+// panel take every block's rank-128 update at once (the chain needs them), everything to the right ONE rank-EP_OUTER update per panel.
+constexpr int EP_OUTER = 4 * GP_NB;
+
 struct gp_ep {
     gp_ctx *ctx = nullptr;
     int n = 0, np = 0;
@@ -34,7 +38,7 @@ struct gp_ep {
     int ldl = 0;
     double *dinv = nullptr;   // np x 16
     double *S = nullptr;      // np x 128 panel of delayed columns
-    double *Sc = nullptr;     // np x 128 panel scaled by c
+    double *Sc = nullptr;     // np x EP_OUTER: the delayed columns scaled by c, one 128-column block per site block of the current outer panel
     double *blk = nullptr;    // 2 x (128 x 128 unit-lower block factor + its 8 tile inverses), by block parity
     double *vec = nullptr;    // 10 x np: tau, nu, tau_old, nu_old, mu, cav_tau, cav_nu, st, tmp1, tmp2
     double *cvec = nullptr;   // 2 x (128 c + 128 coef), by block parity
@@ -43,6 +47,7 @@ struct gp_ep {
     hipEvent_t ev_w = nullptr, ev_pipe = nullptr;   // streamed refactorisation: sweep start on the main stream | its last launch
     int *flags = nullptr;         // np/128 device flags (+ 1 error word): "solved rows of block b are in memory" (ep_block2_kernel -> side stream)
     int epoch = 0;                // token of the current sweep's flags; never reset, so a stale flag cannot match
+    bool owns = true;             // false: a view into an ep_slab (problem g of a lockstep batch); the slab's first problem owns the memory
     bool side_pending = false;    // the side stream still owes the second part of Sigma / mu
     bool sig_mirrored = false;    // the strict upper triangle of Sig mirrors the lower one (only gp_ep_get needs it)
     int *y = nullptr;
@@ -636,7 +641,7 @@ __global__ __launch_bounds__(64 * EP_BLOCK1_WAVES) void ep_block2_kernel(int n, 
                                                                         double *__restrict__ vec, const int *__restrict__ y,
                                                                         double *__restrict__ blk, double *__restrict__ cvbase,
                                                                         double *__restrict__ Scbase, int *__restrict__ flags, int par,
-                                                                        int token, ep_strides es) {
+                                                                        int token, ep_strides es, int scoff) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     constexpr int LS = GP_NB + 1;
     Sig += (size_t)blockIdx.x * es.sig, vec += (size_t)blockIdx.x * es.vec, y += (size_t)blockIdx.x * es.y;
@@ -672,7 +677,7 @@ __global__ __launch_bounds__(64 * EP_BLOCK1_WAVES) void ep_block2_kernel(int n, 
         const double *pL = blk + (size_t)(1 - par) * EP_BLK_ELEMS, *pdinv = pL + GP_NB * GP_NB;     // the block before: unit-lower factor,
         const double *pc = cvbase + (size_t)(1 - par) * 2 * GP_NB;                                  //   its tile inverses, c and coef
         double *X = Sig + i0 + (size_t)(i0 - GP_NB) * np;      // rows of this block, columns of the block before (solved in place)
-        double *X2 = Scbase + i0;                              // X diag(c), leading dimension np
+        double *X2 = Scbase + scoff + i0;                      // X diag(c), leading dimension np, in the column block of the block before
         const double *D = Sig + i0 + (size_t)i0 * np;
         {   // strip by LDS-DMA: one wave instruction = one 128-row column (1 KiB), 32 per wave, all in flight
             const double *src = X + lane * 2 + (size_t)wave * np;
@@ -954,7 +959,8 @@ __global__ void ep_bmat_kernel(double *__restrict__ B, int ldb, const double *__
 // parameters: with M = K + S^-1 only the DIAGONAL of what is factored depends on them, and B = S^1/2 M S^1/2 means
 // chol(B) = S^1/2 chol(M) -- row i of the factor, of the trailing matrix and of nothing else carries the factor s_i.  So the
 // right-looking factorisation can run on unscaled rows and columns for every site that has not been visited yet.
-__global__ void ep_winit_kernel(double *__restrict__ W, int ldw, const double *__restrict__ K, int np) {
+__global__ void ep_winit_kernel(double *__restrict__ W, int ldw, const double *__restrict__ K, int np, size_t sW = 0, size_t sK = 0) {
+    W += (size_t)blockIdx.z * sW, K += (size_t)blockIdx.z * sK;      // blockIdx.z = problem of a lockstep batch
     for (int j = blockIdx.y; j < np; j += gridDim.y) {
         const double *kj = K + (size_t)j * np;
         double *wj = W + (size_t)j * ldw;
@@ -969,7 +975,8 @@ __global__ void ep_winit_kernel(double *__restrict__ W, int ldw, const double *_
 // (blockIdx.y < 128: one column each).  The block's rows of the factor computed so far (columns < k0) take s_i (blockIdx.y >= 128:
 // two columns per workgroup).  One launch for both parts.
 __global__ __launch_bounds__(256) void ep_wscale_kernel(double *__restrict__ W, int ldw, int np, int k0, const double *__restrict__ tau, int n,
-                                                        double *__restrict__ st) {
+                                                        double *__restrict__ st, size_t sW = 0, size_t sVec = 0) {
+    W += (size_t)blockIdx.z * sW, tau += (size_t)blockIdx.z * sVec, st += (size_t)blockIdx.z * sVec;   // blockIdx.z = problem
     if (blockIdx.y < GP_NB) {
         const int k = k0 + blockIdx.y;
         const double sk = (k < n) ? sqrt(tau[k]) : 0.0;
@@ -1073,7 +1080,8 @@ inline dim3 g1(int n) { return dim3((n + 255) / 256); }
 // partial[SYMV_CHUNKS][i]);  then the chunks are added in order.
 constexpr int SYMV_CHUNKS = 16;
 __global__ __launch_bounds__(256) void ep_symv_rows_kernel(const double *__restrict__ A, int ld, int n, const double *__restrict__ x,
-                                                           double *__restrict__ partial, int lo, int m) {
+                                                           double *__restrict__ partial, int lo, int m, size_t sA = 0, size_t sx = 0, size_t sp = 0) {
+    A += (size_t)blockIdx.z * sA, x += (size_t)blockIdx.z * sx, partial += (size_t)blockIdx.z * sp;   // blockIdx.z = problem
     const int r = blockIdx.x * 256 + threadIdx.x;
     if (r >= m) return;
     const int i = lo + r, per = (n + SYMV_CHUNKS - 1) / SYMV_CHUNKS;
@@ -1084,7 +1092,8 @@ __global__ __launch_bounds__(256) void ep_symv_rows_kernel(const double *__restr
     partial[(size_t)blockIdx.y * n + i] = acc;
 }
 __global__ __launch_bounds__(256) void ep_symv_cols_kernel(const double *__restrict__ A, int ld, int n, const double *__restrict__ x,
-                                                           double *__restrict__ partial, int lo, int m) {
+                                                           double *__restrict__ partial, int lo, int m, size_t sA = 0, size_t sx = 0, size_t sp = 0) {
+    A += (size_t)blockIdx.z * sA, x += (size_t)blockIdx.z * sx, partial += (size_t)blockIdx.z * sp;
     const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= m) return;
     const int c = lo + r;
@@ -1100,7 +1109,8 @@ __global__ __launch_bounds__(256) void ep_symv_cols_kernel(const double *__restr
     for (int o = 32; o > 0; o >>= 1) pr += __shfl_xor(pr, o);
     if (lane == 0) partial[(size_t)SYMV_CHUNKS * n + c] = pr;
 }
-__global__ void ep_symv_sum_kernel(const double *__restrict__ partial, int n, double *__restrict__ out, int lo, int m) {
+__global__ void ep_symv_sum_kernel(const double *__restrict__ partial, int n, double *__restrict__ out, int lo, int m, size_t sp = 0, size_t so = 0) {
+    partial += (size_t)blockIdx.z * sp, out += (size_t)blockIdx.z * so;
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= m) return;
     const int i = lo + r;
@@ -1108,10 +1118,12 @@ __global__ void ep_symv_sum_kernel(const double *__restrict__ partial, int n, do
     for (int c = 0; c <= SYMV_CHUNKS; ++c) acc += partial[(size_t)c * n + i];
     out[i] = acc;
 }
-void ep_symv_lower(hipStream_t s, const double *A, int ld, int n, const double *x, double *partial, double *out, int lo, int m) {
-    hipLaunchKernelGGL(ep_symv_rows_kernel, dim3((m + 255) / 256, SYMV_CHUNKS), dim3(256), 0, s, A, ld, n, x, partial, lo, m);
-    hipLaunchKernelGGL(ep_symv_cols_kernel, dim3((m + 3) / 4), dim3(256), 0, s, A, ld, n, x, partial, lo, m);
-    hipLaunchKernelGGL(ep_symv_sum_kernel, dim3((m + 255) / 256), dim3(256), 0, s, partial, n, out, lo, m);
+// count > 1: a lockstep batch (problem g at A + g sA, x / out + g sx, partial + g sp)
+void ep_symv_lower(hipStream_t s, const double *A, int ld, int n, const double *x, double *partial, double *out, int lo, int m, int count = 1,
+                   size_t sA = 0, size_t sx = 0, size_t sp = 0) {
+    hipLaunchKernelGGL(ep_symv_rows_kernel, dim3((m + 255) / 256, SYMV_CHUNKS, count), dim3(256), 0, s, A, ld, n, x, partial, lo, m, sA, sx, sp);
+    hipLaunchKernelGGL(ep_symv_cols_kernel, dim3((m + 3) / 4, 1, count), dim3(256), 0, s, A, ld, n, x, partial, lo, m, sA, sx, sp);
+    hipLaunchKernelGGL(ep_symv_sum_kernel, dim3((m + 255) / 256, 1, count), dim3(256), 0, s, partial, n, out, lo, m, sp, sx);
 }
 
 // end of sweep: L, Sigma, mu from the current site parameters (EpParameterEstimator.scala:56-61)
@@ -1174,7 +1186,8 @@ gp_status ep_join_side(gp_ep *ep) {
 }
 
 // device buffers + labels; K is left for the caller to fill (host upload or device Gram), then ep_start()
-gp_status ep_alloc(gp_ctx *ctx, int n, const int32_t *y, gp_ep **out) {
+// G > 1: every buffer holds G problems back to back (ep_slab); the returned object is problem 0 and owns the memory
+gp_status ep_alloc(gp_ctx *ctx, int n, const int32_t *y, gp_ep **out, int G = 1) {
     *out = nullptr;
     for (int i = 0; i < n; ++i) GP_REQUIRE(ctx, y[i] == 1 || y[i] == -1, "targets must contain values from set {-1,1}");
     GP_HIP(ctx, hipSetDevice(ctx->device));
@@ -1185,16 +1198,16 @@ gp_status ep_alloc(gp_ctx *ctx, int n, const int32_t *y, gp_ep **out) {
     gp_ep *ep = new (std::nothrow) gp_ep();
     if (!ep) return GP_ENOMEM;
     ep->ctx = ctx; ep->n = n; ep->np = gp_pad(n); ep->ldl = 2 * ep->np;
-    const size_t np = ep->np, nn = np * np * sizeof(double);
+    const size_t np = ep->np, nn = (size_t)G * np * np * sizeof(double);
     hipError_t e = hipMalloc(&ep->K, nn);
     if (e == hipSuccess) e = hipMalloc(&ep->Sig, nn);
     if (e == hipSuccess) e = hipMalloc(&ep->L, 2 * nn);
-    if (e == hipSuccess) e = hipMalloc(&ep->dinv, np * 16 * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&ep->dinv, G * np * 16 * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&ep->S, np * GP_NB * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc(&ep->Sc, np * GP_NB * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc(&ep->blk, 2 * (GP_NB * GP_NB + 8 * 256) * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc(&ep->vec, 10 * np * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc(&ep->cvec, 4 * GP_NB * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&ep->Sc, G * np * EP_OUTER * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&ep->blk, (size_t)G * 2 * (GP_NB * GP_NB + 8 * 256) * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&ep->vec, G * 10 * np * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&ep->cvec, (size_t)G * 4 * GP_NB * sizeof(double));
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ep->ev_chol, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ep->ev_parta, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ep->ev_partb, hipEventDisableTiming);
@@ -1204,9 +1217,9 @@ gp_status ep_alloc(gp_ctx *ctx, int n, const int32_t *y, gp_ep **out) {
     for (hipEvent_t &ev : ep->ev)
         if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc(&ep->y, np * sizeof(int));
-    if (e == hipSuccess) e = hipMalloc(&ep->flags, (np / GP_NB + 1) * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc(&ep->flags, (size_t)G * (np / GP_NB + 1) * sizeof(int));
     hipStream_t s = ctx->stream;
-    if (e == hipSuccess) e = hipMemsetAsync(ep->flags, 0, (np / GP_NB + 1) * sizeof(int), s);
+    if (e == hipSuccess) e = hipMemsetAsync(ep->flags, 0, (size_t)G * (np / GP_NB + 1) * sizeof(int), s);
     if (e == hipSuccess) e = hipMemsetAsync(ep->K, 0, nn, s);
     if (e == hipSuccess) e = hipMemsetAsync(ep->L, 0, 2 * nn, s);
     if (e == hipSuccess) e = hipMemsetAsync(ep->y, 0, np * sizeof(int), s);
@@ -1228,6 +1241,184 @@ gp_status ep_start(gp_ep *ep) {
     ep->side_pending = false;
     ep->sweeps = 0;
     GP_HIP(ctx, hipStreamSynchronize(s));
+    return GP_OK;
+}
+
+// Block pb = b - 1's delayed update of the trailing covariance, enqueued on `st` in iteration b (i0 = 128 b: first row / column that
+// still matters).  two == false: Sigma[i0:, i0:] -= Sc S^T (lower), rank 128, everything at once.  two == true (two-level, EP_OUTER
+// columns per outer panel): the rank-128 update only reaches the "near" columns [i0, nl), nl = one block past pb's outer panel -- the
+// columns the chain reads before that panel is complete --, and when pb closes its panel ONE rank-EP_OUTER update brings in
+// everything to the right of nl: a quarter of the read-modify-write traffic on those columns and a GEMM shape (K = 512) that runs at
+// twice the rate of K = 128.  Sc holds the panel's scaled columns side by side (block pb in column block pb % 4), S is in place in
+// Sigma's dead column panels.  bt: lockstep batch (strides A = Sc, B = C = Sigma).
+void ep_trailing_update(gp_ctx *ctx, hipStream_t st, int np, int i0, bool two, double *Sc, double *Sig, gp_batch bt) {
+    const int pb = i0 / GP_NB - 1, jb = pb % (EP_OUTER / GP_NB);
+    const int P0 = pb / (EP_OUTER / GP_NB) * EP_OUTER, pe = std::min(np, P0 + EP_OUTER);
+    const int nl = two ? std::min(np, pe + GP_NB) : np;
+    const int M = np - i0, N = nl - i0;
+    if (M <= GP_NB) return;          // block b is the last one: nothing below or right of it
+    const double tiles = (double)(N / GP_NB) * (M / GP_NB) - (double)(N / GP_NB) * (N / GP_NB - 1) / 2.0;
+    gp_prof_begin(ctx, GP_PROF_GEMM, st);
+    gpk_gemm_nt(st, M, N, GP_NB, -1.0, Sc + (size_t)jb * GP_NB * np + i0, np, Sig + (size_t)i0 + (size_t)(i0 - GP_NB) * np, np, 1.0,
+                Sig + (size_t)i0 + (size_t)i0 * np, np, 1, 0, bt);
+    gp_prof_end(ctx, GP_PROF_GEMM, bt.count * tiles * 2.0 * GP_NB * GP_NB * GP_NB, st);
+    if (two && i0 == pe && nl < np) {
+        const int R = np - nl, Kp = pe - P0;
+        gp_prof_begin(ctx, GP_PROF_SYRK, st);
+        gpk_gemm_nt(st, R, R, Kp, -1.0, Sc + nl, np, Sig + (size_t)nl + (size_t)P0 * np, np, 1.0, Sig + (size_t)nl + (size_t)nl * np, np, 1, 0, bt);
+        gp_prof_end(ctx, GP_PROF_SYRK, (double)bt.count * R * ((double)R + GP_NB) * Kp, st);
+    }
+}
+
+// ---- lockstep batch: G EP problems of one size advance through a sweep together (MeshHyperParamsLogLikelihoodEvaluator.scala:26-40
+// and the trial steps of HyperParamsOptimization.scala:31-55 evaluate independent settings one after the other) ----
+// A single sweep is bound by its serial site chain (one workgroup per block of 128 sites) and by the launch latencies of the ~12
+// small kernels per block that feed it; the matrix work beside it leaves most of the chip idle (C4: 33 of 78 TFLOP/s).  G problems
+// share every launch instead: the chain kernel runs as G workgroups on G CUs (blockIdx.x = problem), the solves, updates and the
+// refactorisation under the site loop as gp_batch launches with G times the tiles -- the same sweep, the same arithmetic per problem
+// (bit for bit: every kernel computes a problem's tiles exactly as in a single run), G times the work per launch latency.
+struct ep_slab {
+    gp_ctx *ctx = nullptr;
+    int n = 0, np = 0, G = 0;
+    std::vector<gp_ep *> ep;        // ep[0] owns the memory, ep[g] views problem g
+    int *info = nullptr;            // G failing-pivot words
+    double *partial = nullptr;      // G x (SYMV_CHUNKS + 1) x np
+    size_t sMat() const { return (size_t)np * np; }
+    size_t sL() const { return (size_t)2 * np * np; }
+    size_t sVec() const { return (size_t)10 * np; }
+    size_t sBlk() const { return (size_t)2 * EP_BLK_ELEMS; }
+    size_t sCv() const { return (size_t)4 * GP_NB; }
+    size_t sSc() const { return (size_t)np * EP_OUTER; }
+    size_t sDinv() const { return (size_t)np * 16; }
+    int sFlag() const { return np / GP_NB + 1; }
+    size_t sPart() const { return (size_t)(SYMV_CHUNKS + 1) * np; }
+};
+
+void ep_slab_free(ep_slab &sl) {
+    if (sl.ctx) (void)hipSetDevice(sl.ctx->device);
+    for (size_t g = sl.ep.size(); g-- > 1;) gp_ep_destroy(sl.ep[g]);
+    if (!sl.ep.empty()) gp_ep_destroy(sl.ep[0]);     // synchronises the context's streams first
+    sl.ep.clear();
+    if (sl.info) (void)hipFree(sl.info);
+    if (sl.partial) (void)hipFree(sl.partial);
+    sl.info = nullptr, sl.partial = nullptr;
+}
+
+gp_status ep_slab_alloc(gp_ctx *ctx, int n, const int32_t *y, int G, ep_slab &sl) {
+    sl.ctx = ctx, sl.n = n, sl.np = gp_pad(n), sl.G = G;
+    gp_ep *e0 = nullptr;
+    GP_TRY(ep_alloc(ctx, n, y, &e0, G));
+    sl.ep.push_back(e0);
+    hipError_t e = hipMalloc(&e0->Sig2, sizeof(double) * G * sl.sMat());
+    if (e == hipSuccess) e = hipMalloc(&sl.info, sizeof(int) * G);
+    if (e == hipSuccess) e = hipMalloc(&sl.partial, sizeof(double) * G * sl.sPart());
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        GP_SET_ERR(ctx, "EP lockstep batch of %d problems (n = %d): out of device memory", G, n);
+        ep_slab_free(sl);
+        return GP_ENOMEM;
+    }
+    for (int g = 1; g < G; ++g) {
+        gp_ep *v = new (std::nothrow) gp_ep();
+        if (!v) { ep_slab_free(sl); return GP_ENOMEM; }
+        v->owns = false, v->ctx = ctx, v->n = n, v->np = sl.np, v->ldl = e0->ldl;
+        v->K = e0->K + g * sl.sMat(), v->Sig = e0->Sig + g * sl.sMat(), v->Sig2 = e0->Sig2 + g * sl.sMat(), v->L = e0->L + g * sl.sL();
+        v->dinv = e0->dinv + g * sl.sDinv(), v->S = e0->S, v->Sc = e0->Sc + g * sl.sSc(), v->blk = e0->blk + g * sl.sBlk();
+        v->vec = e0->vec + g * sl.sVec(), v->cvec = e0->cvec + g * sl.sCv(), v->y = e0->y, v->flags = e0->flags + (size_t)g * sl.sFlag();
+        sl.ep.push_back(v);
+    }
+    return GP_OK;
+}
+
+// ONE sweep of problems 0 .. count-1 of the slab: gp_ep_sweep's fused chain + streamed refactorisation, every launch a batch.
+gp_status ep_sweep_lockstep(ep_slab &sl, int count) {
+    gp_ctx *ctx = sl.ctx;
+    GP_TRY(gpi_ctx_ep_streams(ctx));
+    gp_ep *e0 = sl.ep[0];
+    hipStream_t s = ctx->stream, s2 = ctx->side, s3 = ctx->side2, s4 = ctx->side3;
+    const int n = sl.n, np = sl.np, nblk = np / GP_NB, ldl = e0->ldl;
+    // columns of Vt per next-covariance update: a batch is bound by GEMM throughput, not by the chain, so long updates pay (n = 4096,
+    // 12 problems, K = 256 / 512 / 1024: 229 / 239 / 244 sweeps/s aggregate)
+    const int sig_blocks = [np] { const int v = gp_env_blocks("GPCORE_EP_SIG_K"); return v >= GP_NB ? v / GP_NB : (np >= 4096 ? 8 : 2); }();
+    const bool far_split = [] { const char *e = getenv("GPCORE_EP_FAR"); return !e || atoi(e) != 0; }();
+    // two-level delayed updates (ep_trailing_update): measured equal (n = 4096, 12 problems: 228.9 vs 229.1 sweeps/s aggregate; a single
+    // run 184.7 vs 188.0) -- the site loop's updates are an eighth of a sweep's flops -- so the one-level form stays the default
+    const bool two = [] { const char *e = getenv("GPCORE_EP_TWOLEVEL"); return e && atoi(e) != 0; }();
+    ep_strides es;
+    es.sig = sl.sMat(), es.vec = sl.sVec(), es.y = 0, es.blk = sl.sBlk(), es.cvec = sl.sCv(), es.sc = sl.sSc(), es.flag = sl.sFlag();
+    gp_batch bSig, bTrsm, bVt;
+    bSig.count = bTrsm.count = bVt.count = count;
+    bSig.s0 = sl.sSc(), bSig.s1 = sl.sMat(), bSig.s2 = sl.sMat();                      // C (Sigma) -= A (Sc) B (Sigma's dead panel)^T
+    bTrsm.s0 = sl.sMat(), bTrsm.s1 = sl.sBlk(), bTrsm.s2 = sl.sBlk(), bTrsm.s3 = sl.sSc(), bTrsm.s4 = sl.sCv(), bTrsm.s5 = sl.sVec();
+    bVt.s0 = bVt.s1 = sl.sL(), bVt.s2 = sl.sMat(), bVt.s3 = sl.sMat();                 // Sigma' (+= K the first time) -= Vt Vt^T
+    const int token = ++e0->epoch;
+    int *flag_err = e0->flags + np / GP_NB;        // problem 0's error word collects every problem's
+    GP_HIP(ctx, hipMemsetAsync(sl.info, 0, sizeof(int) * count, s));
+    GP_HIP(ctx, hipMemsetAsync(flag_err, 0, sizeof(int), s));
+    GP_HIP(ctx, hipEventRecord(e0->ev_w, s));
+    GP_HIP(ctx, hipStreamWaitEvent(s3, e0->ev_w, 0));
+    GP_HIP(ctx, hipStreamWaitEvent(s4, e0->ev_w, 0));
+    hipLaunchKernelGGL(ep_winit_kernel, dim3(8, np < 4096 ? np : 4096, count), dim3(256), 0, s3, e0->L, ldl, e0->K, np, sl.sL(), sl.sMat());
+    int b = 0, pend0 = 0;
+    hipEvent_t last_side = nullptr;
+    for (int i0 = 0; i0 < n; i0 += GP_NB, ++b) {
+        const int bsz = (n - i0 < GP_NB) ? n - i0 : GP_NB;
+        const int par = b & 1;
+        double *Lmat = e0->blk + (size_t)par * EP_BLK_ELEMS, *bdinv = Lmat + GP_NB * GP_NB;
+        double *cvec = e0->cvec + (size_t)par * 2 * GP_NB, *ncoef = cvec + GP_NB;
+        if (b >= 2) GP_HIP(ctx, hipStreamWaitEvent(s, e0->ev[4 * (b - 2) + 2], 0));
+        if (b > 0)
+            hipLaunchKernelGGL(ep_block2_kernel<true>, dim3(count), dim3(64 * EP_BLOCK1_WAVES), EP_BLOCK2_LDS, s, n, np, i0, bsz, e0->Sig, e0->vec, e0->y,
+                               e0->blk, e0->cvec, e0->Sc, e0->flags, par, token, es, ((b - 1) % (EP_OUTER / GP_NB)) * GP_NB * np);
+        else
+            hipLaunchKernelGGL(ep_block2_kernel<false>, dim3(count), dim3(64 * EP_BLOCK1_WAVES), EP_BLOCK2_LDS, s, n, np, i0, bsz, e0->Sig, e0->vec, e0->y,
+                               e0->blk, e0->cvec, e0->Sc, e0->flags, par, token, es, 0);
+        hipEvent_t ev_fac = e0->ev[4 * b], ev_vt = e0->ev[4 * b + 3];
+        GP_HIP(ctx, hipEventRecord(ev_fac, s));
+        // refactorisation under the site loop, one block behind it (third and fourth stream)
+        GP_HIP(ctx, hipStreamWaitEvent(s3, ev_fac, 0));
+        {
+            const int gx = (2 * np - i0 + 1023) / 1024;
+            hipLaunchKernelGGL(ep_wscale_kernel, dim3(gx, GP_NB + std::min((i0 / 2 + gx - 1) / gx, 256), count), dim3(256), 0, s3, e0->L, ldl, np, i0,
+                               e0->tau(), n, e0->st(), sl.sL(), sl.sVec());
+        }
+        gpi_chol_panel_step(ctx, s3, e0->L, np, ldl, e0->dinv, np, i0, ev_vt, far_split ? s4 : nullptr, e0->ev_parta, count, sl.sL(), sl.sDinv(), sl.info);
+        if ((b + 1) % sig_blocks == 0 || b >= nblk - 2) {
+            GP_HIP(ctx, hipStreamWaitEvent(s4, ev_vt, 0));
+            const int kw = i0 + GP_NB - pend0;
+            const double *Vb = e0->L + np + (size_t)pend0 * ldl;
+            gp_prof_begin(ctx, GP_PROF_SYRK, s4);
+            gpk_gemm_nt(s4, np, np, kw, -1.0, Vb, ldl, Vb, ldl, 1.0, e0->Sig2, np, 1, 0, bVt, pend0 == 0 ? e0->K : nullptr, np);
+            gp_prof_end(ctx, GP_PROF_SYRK, (double)count * np * ((double)np + GP_NB) * kw, s4);
+            pend0 = i0 + GP_NB;
+        }
+        if (b > 0) {
+            // second stream: block b-1's trailing update of every problem, after every problem's flag
+            if (np - i0 > GP_NB) {
+                hipLaunchKernelGGL(ep_wait_flag_kernel, dim3(count), dim3(1), 0, s2, e0->flags + b, sl.sFlag(), token, flag_err);
+                ep_trailing_update(ctx, s2, np, i0, two, e0->Sc, e0->Sig, bSig);
+            }
+            GP_HIP(ctx, hipEventRecord(e0->ev[4 * (b - 1) + 2], s2));
+            last_side = e0->ev[4 * (b - 1) + 2];
+        }
+        const int r0 = i0 + GP_NB, rt = np - r0;
+        if (rt <= 0 || r0 >= n) continue;
+        const int rest = rt - GP_NB;
+        if (rest > 0) {
+            double *St = e0->Sig + (size_t)r0 + (size_t)i0 * np, *Sct = e0->Sc + (size_t)(b % (EP_OUTER / GP_NB)) * GP_NB * np + r0;
+            GP_HIP(ctx, hipStreamWaitEvent(s2, ev_fac, 0));
+            gpk_trsm_panel128(s2, St + GP_NB, rest, np, Lmat, GP_NB, bdinv, nullptr, ncoef, e0->mu() + r0 + GP_NB, bTrsm, Sct + GP_NB, cvec);
+        }
+    }
+    if (last_side) GP_HIP(ctx, hipStreamWaitEvent(s, last_side, 0));
+    GP_HIP(ctx, hipEventRecord(e0->ev_pipe, s4));
+    GP_HIP(ctx, hipStreamWaitEvent(s, e0->ev_pipe, 0));
+    GP_HIP(ctx, hipEventRecord(e0->ev_chol, s3));
+    GP_HIP(ctx, hipStreamWaitEvent(s, e0->ev_chol, 0));
+    for (gp_ep *v : sl.ep) { std::swap(v->Sig, v->Sig2); v->sig_mirrored = false; }
+    ep_symv_lower(s, e0->Sig, np, np, e0->nu(), sl.partial, e0->mu(), 0, np, count, sl.sMat(), sl.sVec(), sl.sPart());
+    GP_LAUNCH_CHECK(ctx);
+    for (int g = 0; g < count; ++g) sl.ep[g]->sweeps += 1;
     return GP_OK;
 }
 
@@ -1276,6 +1467,8 @@ gp_status gp_ep_sweep(gp_ep *ep, int nsweeps, double *tau, double *nu, int *info
     // profiles/r03_c_sweep_fused.txt), the chain is as much bound by the side stream's solve + updates as by its own kernels, so
     // the default follows the streamed refactorisation (np > 1024); the lockstep batch (ep_sweep_lockstep) always uses it
     const bool fused = overlap && block1 && [pipe] { const char *e = getenv("GPCORE_EP_FUSED"); return e ? atoi(e) != 0 : pipe; }();
+    // two-level delayed updates (ep_trailing_update): GPCORE_EP_TWOLEVEL = 1; off by default (measured equal or slower: ep_sweep_lockstep)
+    const bool two = fused && [] { const char *e = getenv("GPCORE_EP_TWOLEVEL"); return e && atoi(e) != 0; }();
     int *flag_err = ep->flags + np / GP_NB;
     if (fused) GP_HIP(ctx, hipMemsetAsync(flag_err, 0, sizeof(int), s));
     const bool far_split = [] { const char *e = getenv("GPCORE_EP_FAR"); return !e || atoi(e) != 0; }();
@@ -1337,10 +1530,10 @@ gp_status gp_ep_sweep(gp_ep *ep, int nsweeps, double *tau, double *nu, int *info
                 if (b >= 2) GP_HIP(ctx, hipStreamWaitEvent(s, ep->ev[4 * (b - 2) + 2], 0));
                 if (b > 0)
                     hipLaunchKernelGGL(ep_block2_kernel<true>, dim3(1), dim3(64 * EP_BLOCK1_WAVES), EP_BLOCK2_LDS, s, n, np, i0, bsz, ep->Sig, ep->vec,
-                                       ep->y, ep->blk, ep->cvec, ep->Sc, ep->flags, par, token, ep_strides());
+                                       ep->y, ep->blk, ep->cvec, ep->Sc, ep->flags, par, token, ep_strides(), ((b - 1) % (EP_OUTER / GP_NB)) * GP_NB * np);
                 else
                     hipLaunchKernelGGL(ep_block2_kernel<false>, dim3(1), dim3(64 * EP_BLOCK1_WAVES), EP_BLOCK2_LDS, s, n, np, i0, bsz, ep->Sig, ep->vec,
-                                       ep->y, ep->blk, ep->cvec, ep->Sc, ep->flags, par, token, ep_strides());
+                                       ep->y, ep->blk, ep->cvec, ep->Sc, ep->flags, par, token, ep_strides(), 0);
             } else if (block1)
                 hipLaunchKernelGGL(ep_block1_kernel, dim3(1), dim3(64 * EP_BLOCK1_WAVES), EP_BLOCK1_LDS, s, n, np, i0, bsz, ep->Sig, ep->mu(), ep->y,
                                    ep->tau(), ep->nu(), ep->cav_tau(), ep->cav_nu(), cvec, ncoef, Lmat, bdinv);
@@ -1379,20 +1572,17 @@ gp_status gp_ep_sweep(gp_ep *ep, int nsweeps, double *tau, double *nu, int *info
                 // one lower-trapezoid launch.)  Every launch on this stream costs ~40 us while the other streams' GEMMs hold the CUs,
                 // whatever its size (profiles/r03_d_sweep_urgent_first.txt), so the chain's slack is spent on three launches per block
                 // (solve, wait, update), not on five.
-                const int prt = np - i0;
-                if (prt > GP_NB) {
+                if (np - i0 > GP_NB) {
                     hipLaunchKernelGGL(ep_wait_flag_kernel, dim3(1), dim3(1), 0, s2, ep->flags + b, 0, token, flag_err);
-                    gp_prof_begin(ctx, GP_PROF_GEMM, s2);
-                    gpk_gemm_nt(s2, prt, prt, GP_NB, -1.0, ep->Sc + i0, np, ep->Sig + (size_t)i0 + (size_t)(i0 - GP_NB) * np, np, 1.0,
-                                ep->Sig + (size_t)i0 + (size_t)i0 * np, np, 1);
-                    gp_prof_end(ctx, GP_PROF_GEMM, (double)prt * ((double)prt + GP_NB) * GP_NB, s2);
+                    ep_trailing_update(ctx, s2, np, i0, two, ep->Sc, ep->Sig, gp_batch());
                 }
                 GP_HIP(ctx, hipEventRecord(ep->ev[4 * (b - 1) + 2], s2));
                 last_side = ep->ev[4 * (b - 1) + 2];
             }
             const int r0 = i0 + GP_NB, rt = np - r0;
             if (rt <= 0 || r0 >= n) continue;
-            double *St = ep->Sig + (size_t)r0 + (size_t)i0 * np, *Sct = ep->Sc + r0;
+            double *St = ep->Sig + (size_t)r0 + (size_t)i0 * np;
+            double *Sct = ep->Sc + (fused ? (size_t)(b % (EP_OUTER / GP_NB)) * GP_NB * np : (size_t)0) + r0;   // fused: the block's column block of the panel
             double *Ctr = ep->Sig + (size_t)r0 + (size_t)r0 * np;
             if (!overlap) {
                 gpk_trsm_panel128(s, St, rt, np, Lmat, GP_NB, bdinv, nullptr, ncoef, ep->mu() + r0, gp_batch(), Sct, cvec);
@@ -1637,6 +1827,96 @@ gp_status gp_ep_optimize_rbf(gp_ctx *ctx, const double *X, int n, int d, int ldx
     return gpi_lbfgs_maximize(ctx, P, P, theta0, max_iter, history, NC, evaluate, theta_out, lml_out, iters_out, evals_out);
 }
 
+// B settings through lockstep sweeps.  G problems (GPCORE_EP_GROUP, default 12, capped by B and by free device memory: 5 np^2 doubles
+// each) live in one slab; a problem leaves when its stop criterion holds (AvgBasedStopCriterion as written, host side, per problem
+// per sweep) or at max_sweeps, gets its LML (and gradient) from the single-problem entry points on its view of the slab, and its
+// slot takes the next setting -- problems in one launch need not be at the same sweep.  Towards the end the slots above the last
+// active one drop out of the launches; a finished problem below it keeps sweeping (its results are already out).
+static gp_status ep_eval_lockstep(gp_ctx *ctx, const double *X, int n, int d, int ldx, const int32_t *y, const double *thetas, int B,
+                                  double stop_eps, int max_sweeps, int strict, double *lml, double *grad, int *sweeps, int *info) {
+    const int P = d + 2, np = gp_pad(n);
+    GP_HIP(ctx, hipSetDevice(ctx->device));
+    int G = 12;
+    if (const char *e = getenv("GPCORE_EP_GROUP")) G = atoi(e);
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const double per = 5.2 * 8.0 * (double)np * np;
+            G = std::min<long long>(G, (long long)(0.8 * (double)free_b / per));
+        }
+    }
+    G = std::max(1, std::min(G, B));
+    ep_slab sl;
+    GP_TRY(ep_slab_alloc(ctx, n, y, G, sl));
+    double *dX = nullptr;
+    gp_status st = gpi_ws_get(ctx, WS_A, sizeof(double) * (size_t)n * d, &dX);
+    if (st == GP_OK) st = gpi_upload_2d(ctx, dX, n, X, ldx, n, d);
+    std::vector<int> slot_b(G, -1), slot_j(G, 0);
+    std::vector<double> cur((size_t)G * 2 * n, 0.0), old((size_t)G * 2 * n, 0.0), pull((size_t)G * 2 * np);
+    std::vector<int> hinfo(G, 0);
+    int next = 0, active = 0;
+    auto load = [&](int g) -> gp_status {      // the next setting into slot g: Gram on the device, sites zeroed, Sigma = K
+        slot_b[g] = -1;
+        if (next >= B) return GP_OK;
+        const int b = next++;
+        gp_ep *v = sl.ep[g];
+        gpk_gram_sym(ctx->stream, dX, n, d, n, thetas + (size_t)b * P, v->K, np, 1, 0.0);
+        GP_TRY(ep_start(v));
+        slot_b[g] = b, slot_j[g] = 0;
+        std::fill(cur.begin() + (size_t)g * 2 * n, cur.begin() + (size_t)(g + 1) * 2 * n, 0.0);
+        ++active;
+        return GP_OK;
+    };
+    for (int g = 0; g < G && st == GP_OK; ++g) st = load(g);
+    while (st == GP_OK && active > 0) {
+        int count = 0;
+        for (int g = 0; g < G; ++g) if (slot_b[g] >= 0) count = g + 1;
+        st = ep_sweep_lockstep(sl, count);
+        if (st != GP_OK) break;
+        // tau | nu of every problem (the first 2 np doubles of its vector block) and the failing-pivot words, after ONE synchronisation
+        hipError_t e = hipMemcpy2DAsync(pull.data(), sizeof(double) * 2 * np, sl.ep[0]->vec, sizeof(double) * sl.sVec(), sizeof(double) * 2 * np, count,
+                                        hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(hinfo.data(), sl.info, sizeof(int) * count, hipMemcpyDeviceToHost, ctx->stream);
+        int ferr = 0;
+        if (e == hipSuccess) e = hipMemcpyAsync(&ferr, sl.ep[0]->flags + np / GP_NB, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) { GP_SET_ERR(ctx, "EP lockstep batch: %s", hipGetErrorString(e)); st = GP_EHIP; break; }
+        if (ferr) { GP_SET_ERR(ctx, "EP lockstep sweep: a device flag of the fused chain did not arrive within its bound (problem %d)", ferr - 1); st = GP_EHIP; break; }
+        for (int g = 0; g < count && st == GP_OK; ++g) {
+            const int b = slot_b[g];
+            if (b < 0) continue;
+            double *tn = cur.data() + (size_t)g * 2 * n, *to = old.data() + (size_t)g * 2 * n;
+            std::copy(tn, tn + 2 * n, to);
+            std::copy(pull.begin() + (size_t)g * 2 * np, pull.begin() + (size_t)g * 2 * np + n, tn);                 // tau
+            std::copy(pull.begin() + (size_t)g * 2 * np + np, pull.begin() + (size_t)g * 2 * np + np + n, tn + n);   // nu
+            const int j = ++slot_j[g];
+            bool done = j >= max_sweeps, bad = hinfo[g] != 0;
+            if (!done && !bad && stop_eps >= 0.0) {   // avgBetweenSiteParams :195-202: (sum / 2) * n, precedence as written
+                double sum = 0.0;
+                for (int i = 0; i < n; ++i) sum = sum + (tn[n + i] - to[n + i]) + (tn[i] - to[i]);
+                done = std::fabs(sum / 2 * n) < stop_eps;
+            }
+            if (!done && !bad) continue;
+            gp_ep *v = sl.ep[g];
+            if (bad) {
+                lml[b] = NAN;
+                if (grad) for (int q = 0; q < P; ++q) grad[(size_t)b * P + q] = NAN;
+                if (info) info[b] = hinfo[g];
+            } else {
+                st = gp_ep_lml(v, strict, lml + b);
+                if (st == GP_OK && grad) st = ep_lml_grad_dev(v, dX, d, thetas + (size_t)b * P, strict, grad + (size_t)b * P);
+                if (info) info[b] = 0;
+            }
+            if (sweeps) sweeps[b] = j;
+            --active;
+            if (st == GP_OK) st = load(g);
+            if (st == GP_OK && slot_b[g] < 0 && bad) st = ep_start(v);     // a failed problem that stays in the launches: back to a benign state
+        }
+    }
+    ep_slab_free(sl);
+    return st;
+}
+
 static gp_status ep_eval_batched(gp_ctx *ctx, const double *X, int n, int d, int ldx, const int32_t *y, const double *thetas, int B,
                                  double stop_eps, int max_sweeps, int strict, double *lml, double *grad, int *sweeps, int *info) {
     if (!ctx) return GP_EINVAL;
@@ -1644,6 +1924,15 @@ static gp_status ep_eval_batched(gp_ctx *ctx, const double *X, int n, int d, int
     GP_REQUIRE(ctx, n >= 1 && d >= 1 && d <= 64 && ldx >= n && B >= 0 && max_sweeps >= 1, "bad dimensions");
     if (B == 0) return GP_OK;
     const int P = d + 2;
+    {   // lockstep batch (ep_sweep_lockstep) whenever there are two settings and two site blocks; GPCORE_EP_LOCKSTEP = 0 selects the
+        // one-setting-at-a-time path below.  12 settings x 10 sweeps, aggregate sweeps/s one at a time -> lockstep (profiles/r03_m_ep_mesh_perf.log,
+        // r03_k_ep_mesh_perf2.log): n = 512 1778 -> 12110, n = 1024 831 -> 6081, n = 1536 570 -> 3028, n = 2048 416 -> 1600, n = 4096 184 -> 244
+        // (44.7 TFLOP/s executed: bound by the batched GEMMs, kernel stats in profiles/r03_k_lockstep_kernel_stats.csv), n = 8192 28.9 -> 30.5
+        const char *e = getenv("GPCORE_EP_LOCKSTEP");
+        const bool lock = e ? atoi(e) != 0 : B >= 2;
+        if (lock && gp_pad(n) >= 2 * GP_NB)
+            return ep_eval_lockstep(ctx, X, n, d, ldx, y, thetas, B, stop_eps, max_sweeps, strict, lml, grad, sweeps, info);
+    }
     // Concurrent EP problems, each on its own context: with the streamed refactorisation one run keeps four streams busy and a second
     // one only gets in its way (12 settings x 10 sweeps, aggregate sweeps/s with 1 / 2 / 3 workers: n = 2048 397 / 171 / 184, n = 4096
     // 177 / 69 / 80); the end-of-sweep form of the small problems still gains from a second run (n = 512 1270 / 1499 / 1061, n = 1024
@@ -1724,6 +2013,7 @@ gp_status gp_debug_ep_stamps(unsigned long long *out) {
 
 void gp_ep_destroy(gp_ep *ep) {
     if (!ep) return;
+    if (!ep->owns) { delete ep; return; }
     if (ep->ctx) {
         (void)hipSetDevice(ep->ctx->device);
         for (hipStream_t st : {ep->ctx->stream, ep->ctx->side, ep->ctx->side2, ep->ctx->side3}) if (st) (void)hipStreamSynchronize(st);

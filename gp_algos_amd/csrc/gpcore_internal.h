@@ -87,6 +87,9 @@ void gp_prof_end(gp_ctx *ctx, int cls, double work, hipStream_t s = nullptr);
 struct gp_batch {
     int count = 1;
     size_t s0 = 0, s1 = 0, s2 = 0;
+    // further strides, each named by the launcher that uses it: gpk_gemm_nt s3 = Cin; gpk_trsm_panel128 s3 = X2, s4 = tvec and cs2 (one
+    // small per-problem buffer holds both), s5 = dots
+    size_t s3 = 0, s4 = 0, s5 = 0;
     int tri = 0;   // trsm_panel128 only: problem g touches rows [0, (g+1)*128) -- the block columns of an upper-triangular matrix
 };
 
@@ -96,7 +99,7 @@ struct gp_batch {
 // ktri != 0: A(i,k) is zero for k < i (upper-triangular operand): each tile starts its k loop at its row block.
 void gpk_gemm_nt(hipStream_t s, int M, int N, int K, double alpha, const double *A, int lda, const double *B, int ldb,
                  double beta, double *C, int ldc, int lower, int ktri = 0, gp_batch bt = gp_batch(),   // strides: A, B, C
-                 const double *Cin = nullptr, int ldcin = 0);   // beta term read from Cin instead of C (C = beta*Cin + alpha*A*B^T, single problem)
+                 const double *Cin = nullptr, int ldcin = 0);   // beta term read from Cin instead of C (C = beta*Cin + alpha*A*B^T; batch stride bt.s3)
 // C (M x N; lower != 0: the lower trapezoid, i >= j on its diagonal tiles) -= A (M x 128) B (N x 128)^T (K a multiple of 32) on 64 x 64 tiles: the
 // latency-bound updates of a single factorisation -- few 128 x 128 tiles, short K (M, N multiples of 64)
 void gpk_gemm_k128_sub(hipStream_t s, int M, int N, const double *A, int lda, const double *B, int ldb, double *C, int ldc, int lower, int K = 128);
@@ -152,7 +155,7 @@ void gpk_potrf_diag128(hipStream_t s, double *A, int lda, double *dinv_k, int *d
 void gpk_ep_link(hipStream_t s, double *X, int ldx, const double *Lmat, const double *dinv, const double *tvec, double *dots, double *X2,
                  const double *cs2, double *D, int ldd);
 void gpk_trsm_panel128(hipStream_t s, double *X, int M, int ldx, const double *Lkk, int ldl, const double *dinv_k, double *sumsq,
-                       const double *tvec = nullptr, double *dots = nullptr, gp_batch bt = gp_batch(),   // strides: X, Lkk, dinv (no fused reductions when batched)
+                       const double *tvec = nullptr, double *dots = nullptr, gp_batch bt = gp_batch(),   // strides: X, Lkk, dinv; s3 X2, s4 tvec / cs2, s5 dots (sumsq: single problems only)
                        double *X2 = nullptr, const double *cs2 = nullptr);   // optional second output X2(p,c) = X(p,c) * cs2[c] (same ld as X)
 void gpk_fwd_step(hipStream_t s, const double *L, int ldl, const double *dinv_k, double *t, double *sol, int k0, int r);
 void gpk_bwd_step(hipStream_t s, const double *L, int ldl, const double *dinv_k, double *t, double *sol, int k0);
@@ -179,7 +182,8 @@ void gpi_chol_blocked(gp_ctx *ctx, double *A, int np, int lda, double *dinv, int
 // one 128-column step (diagonal block k0) of the same two-level factorisation on stream s, for callers that feed the columns
 // one block at a time: diagonal factor, panel solve, in-panel update, and the K = OUTER trailing update when k0 closes an outer panel
 void gpi_chol_panel_step(gp_ctx *ctx, hipStream_t s, double *A, int np, int lda, double *dinv, int extra, int k0, hipEvent_t solved = nullptr,
-                         hipStream_t far = nullptr, hipEvent_t far_done = nullptr);
+                         hipStream_t far = nullptr, hipEvent_t far_done = nullptr,
+                         int count = 1, size_t strideA = 0, size_t strideDinv = 0, int *info = nullptr);   // count > 1: a lockstep batch (info + g per problem)
 void gpi_solve_rows_lower(gp_ctx *ctx, double *Vt, int mp, const double *L, int np, int ldl, const double *dinv, double *sumsq,
                           const double *tvec = nullptr, double *dots = nullptr);
 void gpi_back_solve_vec(gp_ctx *ctx, const double *L, int np, int ldl, const double *dinv, double *z, double *alpha);

@@ -251,6 +251,10 @@ __global__ __launch_bounds__(256, 2) void trsm_panel128_kernel(double *__restric
     X += (size_t)blockIdx.y * bt.s0;      // blockIdx.y = problem of a lockstep batch
     L += (size_t)blockIdx.y * bt.s1;
     dinv += (size_t)blockIdx.y * bt.s2;
+    if (X2) X2 += (size_t)blockIdx.y * bt.s3;
+    if (cs2) cs2 += (size_t)blockIdx.y * bt.s4;
+    if (tvec) tvec += (size_t)blockIdx.y * bt.s4;
+    if (dots) dots += (size_t)blockIdx.y * bt.s5;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
     const int row0 = blockIdx.x * 64;

@@ -112,7 +112,8 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void gemm_nt_f64_kernel(int M, int
     A += (size_t)prob * bt.s0;
     B += (size_t)prob * bt.s1;
     C += (size_t)prob * bt.s2;
-    if (!Cin) { Cin = C; ldcin = ldc; }   // the beta term is read from C itself unless the caller names another source (single problems only)
+    if (!Cin) { Cin = C; ldcin = ldc; }   // the beta term is read from C itself unless the caller names another source
+    else Cin += (size_t)prob * bt.s3;
     const int row0 = bi * TM, col0 = bj * TN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int NT = (NW == 8) ? 2 : 4;          // 16-column accumulator tiles per wave (8 waves: 64 x 32 per wave)

@@ -371,6 +371,26 @@ def test_ep_sweeps_vs_oracle(ctx, n, sweeps):
     ep.close()
 
 
+def test_ep_two_level_delayed_updates_are_the_same_sweep(ctx, monkeypatch):
+    """GPCORE_EP_TWOLEVEL = 1: the site loop's rank-128 updates reach only the columns the chain reads before the current outer panel of 512
+    columns is complete; everything to the right takes one rank-512 update per panel (ep_trailing_update).  Same sums, grouped
+    differently: equal to the one-level form to rounding, and to the oracle at TOL_EP.  n = 1100: three outer panels, the last one short."""
+    from gp_algos_amd import _lib as L
+    from gp_algos_amd.core import EpClassifierState
+    p, K, y = _ep_problem(1100, seed=71)
+    got = {}
+    for two in ("1", "0"):
+        monkeypatch.setenv("GPCORE_EP_TWOLEVEL", two)
+        ep = EpClassifierState(ctx, K, y)
+        tau, nu = ep.sweep(3)
+        got[two] = dict(tau=tau, nu=nu, mu=ep.get(L.GP_EP_GET_MU), Sigma=ep.get(L.GP_EP_GET_SIGMA), L=ep.get(L.GP_EP_GET_L))
+        ep.close()
+    o = orc.ep_estimate(K, y, 3)
+    for key in ("tau", "nu", "mu", "Sigma", "L"):
+        assert np.max(np.abs(got["1"][key] - got["0"][key])) <= 1e-11 * np.max(np.abs(got["0"][key])), key
+        assert np.max(np.abs(got["1"][key] - o[key])) <= TOL_EP * np.max(np.abs(o[key])), key
+
+
 @pytest.mark.parametrize("n,pipeline,block", [(300, "0", "1"), (300, "1", "1"), (300, "1", "0"), (420, "1", "1")])
 def test_ep_50_sweeps_vs_oracle(ctx, monkeypatch, n, pipeline, block):
     """BASELINE config C4's sweep count against the LITERAL rank-1 loop of EpParameterEstimator.scala:40-62:

@@ -1,5 +1,7 @@
 """Throughput of gp_ep_lml_rbf_batched (EP LML over a grid of settings), C4-sized problem: n=4096, d=8.
-usage: python tools/ep_mesh_perf.py [B] [sweeps] [n]   (env GPCORE_EP_WORKERS selects the concurrency)"""
+usage: python tools/ep_mesh_perf.py [B] [sweeps] [n] [grad]
+env: GPCORE_EP_LOCKSTEP=0 one setting at a time (the serial aggregate), default / 1 the lockstep batch (GPCORE_EP_GROUP slots);
+     GPCORE_EP_WORKERS concurrency of the serial path; grad = 1 also times gp_ep_lml_grad_rbf_batched."""
 import os
 import sys
 import time
@@ -20,5 +22,12 @@ ctx.ep_lml_rbf_batched(p["X"], p["y"], thetas[:3], stop_eps=-1.0, max_sweeps=2) 
 t0 = time.perf_counter()
 lml, sw, info = ctx.ep_lml_rbf_batched(p["X"], p["y"], thetas, stop_eps=-1.0, max_sweeps=sweeps)
 dt = time.perf_counter() - t0
-print("n=%d workers=%s B=%d sweeps=%d: %.1f ms -> %.2f settings/s, %.1f sweeps/s aggregate; lml[0]=%.6f info=%s" %
-      (n, os.environ.get("GPCORE_EP_WORKERS", "default"), B, sweeps, dt * 1e3, B / dt, B * sweeps / dt, lml[0], info.tolist()))
+print("n=%d lockstep=%s group=%s workers=%s B=%d sweeps=%d: %.1f ms -> %.2f settings/s, %.1f sweeps/s aggregate; lml[0]=%.9f lml[-1]=%.9f info=%s" %
+      (n, os.environ.get("GPCORE_EP_LOCKSTEP", "default"), os.environ.get("GPCORE_EP_GROUP", "default"), os.environ.get("GPCORE_EP_WORKERS", "default"),
+       B, sweeps, dt * 1e3, B / dt, B * sweeps / dt, lml[0], lml[-1], sorted(set(info.tolist()))))
+if len(sys.argv) > 4 and sys.argv[4] == "1":
+    t0 = time.perf_counter()
+    lml, grad, sw, info = ctx.ep_lml_grad_rbf_batched(p["X"], p["y"], thetas, stop_eps=-1.0, max_sweeps=sweeps, strict=False)
+    dt = time.perf_counter() - t0
+    print("   with the gradient (Alg. 5.2): %.1f ms -> %.2f settings/s, %.1f sweeps/s aggregate; |grad[0]|=%.6e" % (dt * 1e3, B / dt, B * sweeps / dt,
+                                                                                                               float(np.linalg.norm(grad[0]))))
