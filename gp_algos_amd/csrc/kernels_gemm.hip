@@ -533,7 +533,16 @@ void gpk_gemm_nt_rowred(hipStream_t s, int M, int N, int K, const double *A, int
     // 128-row tiles); an odd 128-row remainder goes through the 8-wave kernel below
     static const bool fused = [] { const char *e = getenv("GPCORE_GEMM_FUSED"); return !e || atoi(e) != 0; }();
     if (fused && M >= FM) {
-        const int Mf = M / FM * FM;
+        // One workgroup per CU: a launch costs whole ROUNDS of num_cu tiles, whatever the last round holds.  Full rounds go to the
+        // 256-row kernel; of what is left, up to num_cu 128-row tiles are cheaper on the 8-wave kernel below (one workgroup per CU on
+        // half a tile's work: 0.55-0.6 of a round) than a 256-row round that is at most half full.  (Config C5: the last batch of a
+        // 10^6-point request, 82 496 rows = 322 tiles, cost two rounds -- as much as a full batch of 131 072; profiles/r03_n_c5_*.)
+        static const int ncu = [] { int dev = 0; hipDeviceProp_t pr; return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }();
+        int Mf = M / FM * FM;
+        const int rem_tiles = (Mf / FM) % ncu;
+        if (Mf / FM > ncu && rem_tiles > 0 && rem_tiles * 2 <= ncu) Mf -= rem_tiles * FM;      // the partial round goes to the 128-row kernel
+        else if (Mf / FM < ncu && Mf / FM * 2 <= ncu / 2) Mf = 0;                               // a lone quarter round or less: 128-row tiles fill more CUs
+        if (Mf == 0) goto small_tiles;
         gemm_rowred r2;
         r2.sumsq = sumsq, r2.tvec = tvec, r2.dots = dots;
         static const bool w8 = [] { const char *e = getenv("GPCORE_FUSED_WAVES"); return !(e && atoi(e) == 16); }();   // 8 waves x 64x64 measured +0.6 % over 16 x 64x32 (a third fewer LDS fragment reads; the loop is power-limited)
@@ -545,6 +554,7 @@ void gpk_gemm_nt_rowred(hipStream_t s, int M, int N, int K, const double *A, int
         A += Mf, C += Mf, sumsq += Mf, M -= Mf;
         if (dots) dots += Mf;
     }
+small_tiles:
     static const int nw = [] { const char *e = getenv("GPCORE_GEMM_WAVES"); return (e && atoi(e) == 4) ? 4 : 8; }();
     gemm_rowred rr;
     rr.sumsq = sumsq, rr.tvec = tvec, rr.dots = dots;
