@@ -116,7 +116,37 @@ def _cholesky_block(n, t_fit, t_fit_serial, o_k, o_ms, o_work, p_k, p_ms, p_work
     return out
 
 
-def _roofline_from_profile(ctx, L, classes, names):
+PMC_TAG = "r03"          # profiles/<PMC_TAG>_pmc_<workload>_summary.json: the committed rocprofv3 --pmc passes of this round (tools/collect_evidence.sh)
+CLASS_SYMBOLS = {        # kernel symbols behind a profile class, as tools/pmc_summary.py abbreviates them
+    "gemm": ("gemm_nt_f64_kernel<0,", "gemm_fused_kernel<"),
+    "syrk": ("gemm_nt_f64_kernel<1,", "gemm_k128_kernel<1>"),
+    "panel": ("gemm_nt_f64_kernel<1,1", "gemm_k128_kernel<1>"),
+}
+
+
+def _pmc_traffic(workload, prefixes):
+    """HBM bytes per launch of the kernels behind a profile class, from the committed PMC passes of the same bench command
+    (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE, MI355X_MICROARCH.md): launch-weighted mean over the matching
+    symbols.  PMC counters cannot be read from inside the process: None when the summary file is missing."""
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "%s_pmc_%s_summary.json" % (PMC_TAG, workload))))
+    except Exception:
+        return None
+    tot, cnt, used = 0.0, 0, []
+    for sym, e in pm.get("kernels", {}).items():
+        if not sym.startswith(tuple(prefixes)) or "hbm_bytes_per_launch_corrected" not in e:
+            continue
+        k = int(e.get("launches_FETCH_SIZE", 0))
+        tot += e["hbm_bytes_per_launch_corrected"] * k
+        cnt += k
+        used.append(sym)
+    if not cnt:
+        return None
+    return {"bytes_per_launch": tot / cnt, "launches_in_pmc_run": cnt, "symbols": sorted(used),
+            "source": "profiles/%s_pmc_%s_summary.json" % (PMC_TAG, workload)}
+
+
+def _roofline_from_profile(ctx, L, classes, names, workload=None):
     """The kernel class that took the most stream time during the timed steps (HIP events recorded by the library around every
     launch of that class, on the stream the launch went to): achieved = algorithmic flops of its launches / their summed time."""
     best = None
@@ -128,9 +158,17 @@ def _roofline_from_profile(ctx, L, classes, names):
         return None
     cls, k, ms, work = best
     tf = work / (ms * 1e-3) / 1e12
-    return {"kernel": names[cls], "bound": "mfma", "achieved": tf, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": tf / PEAK_FP64_MFMA_TFLOPS, "traffic": None, "launches": k, "avg_launch_us": ms / k * 1e3,
-            "flops_per_launch_avg": work / k, "class_time_ms": ms}
+    key = {L.GP_PROF_GEMM: "gemm", L.GP_PROF_SYRK: "syrk", L.GP_PROF_PANEL_UPD: "panel"}.get(cls)
+    pmc = _pmc_traffic(workload, CLASS_SYMBOLS[key]) if (workload and key) else None
+    out = {"kernel": names[cls], "bound": "mfma", "achieved": tf, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
+           "frac": tf / PEAK_FP64_MFMA_TFLOPS, "traffic": pmc["bytes_per_launch"] if pmc else None, "launches": k,
+           "avg_launch_us": ms / k * 1e3, "flops_per_launch_avg": work / k, "class_time_ms": ms}
+    if pmc:
+        # an MFMA-bound product C -= A B^T on 128 x 128 tiles moves at least 16 B of C per 2 K flops per element: what the counters
+        # add to that is operand re-reads
+        out["traffic_unit"] = "HBM bytes per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE), launch-weighted over %s; %s" % (pmc["symbols"], pmc["source"])
+        out["flops_per_hbm_byte"] = (work / k) / pmc["bytes_per_launch"]
+    return out
 
 
 def run_secondary(args):
@@ -216,7 +254,7 @@ def run_secondary(args):
         ctx.profile(0)
         dt = gdist.max_over_ranks(t_rank, device=coll_dev)
         times = gdist.all_gather_rows(np.array([[t_rank]]), world, device=coll_dev) if world > 1 else np.array([[t_rank]])
-        roof = _roofline_from_profile(ctx, L, (L.GP_PROF_GEMM, L.GP_PROF_SYRK), names)
+        roof = _roofline_from_profile(ctx, L, (L.GP_PROF_GEMM, L.GP_PROF_SYRK), names, "c5")
         if rank == 0:
             var = full[:, 1]
             print(json.dumps({"metric": "posterior variances/sec at n=%d fp64 (L resident)" % n, "value": m_total * args.steps / dt,
@@ -252,7 +290,7 @@ def run_secondary(args):
         names_c4[L.GP_PROF_SYRK] = ("gemm_nt_f64_kernel<1,*> / gemm_k128_kernel<1> (lower-trapezoid products of the refactorisation that runs under "
                                     "the site loop: K = 512 trailing updates, next covariance -= Vt Vt^T; launched on two side streams, so a "
                                     "launch shares the chip with up to three other streams and its duration includes that sharing)")
-        roof = _roofline_from_profile(ctx, L, (L.GP_PROF_GEMM, L.GP_PROF_SYRK, L.GP_PROF_PANEL_UPD), names_c4)
+        roof = _roofline_from_profile(ctx, L, (L.GP_PROF_GEMM, L.GP_PROF_SYRK, L.GP_PROF_PANEL_UPD), names_c4, "c4")
         if rank == 0:
             tf = (13.0 / 3.0) * float(n) ** 3 * sweeps * args.steps / dt / 1e12    # 4 1/3 n^3 per sweep
             tf_exec = (8.0 / 3.0) * float(n) ** 3 * sweeps * args.steps / dt / 1e12
@@ -263,9 +301,11 @@ def run_secondary(args):
                                                      "does not shard)" % (n, sweeps), "n": n, "sweeps": sweeps},
                               "algorithmic_tflops": tf, "frac_of_fp64_mfma_peak": tf / PEAK_FP64_MFMA_TFLOPS,
                               "executed_tflops": tf_exec, "executed_frac_of_fp64_mfma_peak": tf_exec / PEAK_FP64_MFMA_TFLOPS,
-                              "critical_path_note": "a sweep is bound by the serial site chain (one single-workgroup kernel per 128 sites, "
-                                                    "~0.70 us per site: a chain of dependent fp64 operations), not by a throughput roofline; "
-                                                    "all matrix work runs on three side streams under it (profiles/: sweep summary)",
+                              "critical_path_note": "a sweep is bound by the serial site chain (ONE single-workgroup kernel per 128 sites: the link to "
+                                                    "the block before as its prologue, then ~0.58 us per site, a chain of dependent fp64 "
+                                                    "operations), not by a throughput roofline; all matrix work runs on three side streams under "
+                                                    "it (profiles/: sweep summary, phase stamps of the chain kernel).  A grid of settings runs in "
+                                                    "lockstep instead (gp_ep_lml_rbf_batched: profiles/*ep_mesh_perf*)",
                               "executed_flops_note": "the sweep executes 2 2/3 n^3 (trailing-only rank-128 updates n^3/3, Cholesky n^3/3, "
                                                      "V n^3, Sigma n^3), the 4 1/3 n^3 of SURVEY 8(d) counts full-square rank-1 updates",
                               "roofline": roof,
@@ -322,7 +362,7 @@ def measure_c3(ctx, n, d, steps, warmup, rank, world, local_rank, backend, coll_
     ctx.profile(0)
     dt = gdist.max_over_ranks(t_rank, device=coll_dev)
     times = gdist.all_gather_rows(np.array([[t_rank]]), world, device=coll_dev) if world > 1 else np.array([[t_rank]])
-    roof = _roofline_from_profile(ctx, L, (L.GP_PROF_GEMM, L.GP_PROF_SYRK, L.GP_PROF_PANEL_UPD), names)
+    roof = _roofline_from_profile(ctx, L, (L.GP_PROF_GEMM, L.GP_PROF_SYRK, L.GP_PROF_PANEL_UPD), names, "c3")
     # spot check outside the timed region: one setting alone (count = 1 forms of every step) against its lockstep result
     b0 = lo if hi > lo else 0
     one, gone, _ = ctx.lml_grad_batched(p["X"], p["y"], p["thetas"][b0:b0 + 1])
@@ -396,7 +436,7 @@ def self_launch(gpus, argv, dry=False):
     return rc
 
 
-PMC_SUMMARY = "r02_c_pmc_c2_summary.json"
+PMC_SUMMARY = PMC_TAG + "_pmc_c2_summary.json"
 DOMINANT_KERNEL = "gemm_fused_kernel<0,0,1,8>"
 
 

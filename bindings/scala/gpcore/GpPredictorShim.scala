@@ -102,6 +102,12 @@ class GpPredictor(val kernelFunc: KernelFunc) {
         val x = dense(trainingData); val xs = dense(testData)
         Native.posteriorFromFactor(ctx, x.data, x.offset, n, x.cols, x.majorStride, rbf.hyperParams.toDenseVector.toArray,
           lc.data, lc.offset, lc.majorStride, alphaVec.toArray, xs.data, xs.offset, m, xs.majorStride, mean, null, cov, v)
+      case co2: Co2Kernel =>          // K* and K** on the device as well (gp_cross_gram_co2 / gp_gram_co2), then the same solves
+        val th = co2.hyperParams.toDenseVector.toArray
+        val ks = new Array[Double](m * n); val kss = new Array[Double](m * m)
+        Native.crossGramCo2(ctx, column(testData), m, column(trainingData), n, th, ks)
+        Native.gramCo2(ctx, column(testData), m, th, kss)
+        Native.posteriorFromGram(ctx, ks, m, n, kss, lc.data, lc.offset, lc.majorStride, alphaVec.toArray, mean, cov, v)
       case other =>
         val ks = MatrixUtils.buildKernelMatrix(other, testData, trainingData)
         val kss = MatrixUtils.buildKernelMatrix(other, testData)
