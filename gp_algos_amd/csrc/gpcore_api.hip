@@ -73,6 +73,11 @@ gp_status read_info(gp_ctx *ctx, int *info) {
     int h = 0;
     GP_HIP(ctx, hipMemcpyAsync(&h, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     GP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (h < 0) {   // chol_wait_flag_kernel gave up (chol_fused): never seen on real hardware queues, reported rather than hung
+        if (info) *info = 0;
+        GP_SET_ERR(ctx, "Cholesky: a device flag of the fused diagonal chain did not arrive within its bound");
+        return GP_EHIP;
+    }
     if (info) *info = h;
     return GP_OK;
 }
@@ -109,6 +114,112 @@ void gemm_sub_single(hipStream_t s, int M, int N, int K, const double *A, int ld
 //       stream, under the next panel's chain of single-workgroup kernels (which need a whole CU's LDS: the mask keeps CUs free).
 // `extra` (0 or GP_NB) rows below the matrix ride along: with y^T in row np this leaves (L^-1 y)^T there.
 // count > 1: a lockstep batch -- problem g lives at A + g*strideA, dinv + g*strideDinv, info + g; every launch covers all of them.
+// Per-step resources of the fused diagonal chain (chol_fused): 2 events per 128-column step + 2 spare, one flag per step
+bool chol_fused_reserve(gp_ctx *ctx, int nblk) {
+    if (ctx->cflags_cap < nblk) {
+        if (ctx->d_cflags) (void)hipFree(ctx->d_cflags);
+        ctx->d_cflags = nullptr, ctx->cflags_cap = 0;
+        if (hipMalloc(&ctx->d_cflags, sizeof(int) * (size_t)nblk) != hipSuccess) { (void)hipGetLastError(); return false; }
+        if (hipMemset(ctx->d_cflags, 0, sizeof(int) * (size_t)nblk) != hipSuccess) return false;
+        ctx->cflags_cap = nblk;
+    }
+    while ((int)ctx->chol_ev.size() < 2 * nblk + 2) {
+        hipEvent_t ev = nullptr;
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return false;
+        ctx->chol_ev.push_back(ev);
+    }
+    return true;
+}
+
+// Single factorisation with ONE launch per step on its diagonal chain (potrf_link128_kernel): within an outer panel, step k's kernel
+// first solves its own 128 rows of block column k-1 and applies them to its diagonal block (what the panel solve and the in-panel
+// update did for it: two launches of the old chain), then factors.  The rest of step k-1 -- the panel solve of the rows below
+// block k, the in-panel update of everything but block k's diagonal tile -- runs on a helper stream beside it: the solve as soon as
+// step k-1's diagonal block is factored, the update as soon as step k's kernel has announced its solved rows (device flag, bounded
+// wait); step k+1's kernel waits for that update.  Outer panels as in chol_blocked: K = OUTER update of the next panel's columns on
+// the main stream, of everything to the right on the CU-masked side stream under the next panel's chain.
+//   old chain per step: diagonal block 24.5 us -> panel solve 13.8 -> in-panel update 22.4, three dependent launches
+//   new chain per step: one launch (link ~20 us + factorisation 24.5 us); solve + update of the rest run beside it
+void chol_fused(gp_ctx *ctx, double *A, int np, int lda, double *dinv, int extra, int OUTER, bool lookahead) {
+    hipStream_t s = ctx->stream, sF = ctx->side, sA = ctx->side2;
+    const int rows = np + extra, nblk = np / GP_NB;
+    int *info = ctx->d_info;
+    const int token = ++ctx->chol_epoch;
+    hipEvent_t ev_join = ctx->chol_ev[2 * nblk], ev_start = ctx->chol_ev[2 * nblk + 1];
+    (void)hipEventRecord(ev_start, s);
+    (void)hipStreamWaitEvent(sA, ev_start, 0);      // the helper stream starts behind whatever the main stream holds now
+    bool side_busy = false;
+    for (int K0 = 0; K0 < np; K0 += OUTER) {
+        const int wcols = std::min(OUTER, np - K0), pe = K0 + wcols;
+        for (int k0 = K0; k0 < pe; k0 += GP_NB) {
+            const int b = k0 / GP_NB;
+            const bool first = k0 == K0, last = k0 + GP_NB == pe;
+            double *Akk = A + (size_t)k0 + (size_t)k0 * lda;
+            double *dk = dinv + (size_t)k0 * 16;
+            hipEvent_t ev_fac = ctx->chol_ev[2 * b], ev_side = ctx->chol_ev[2 * b + 1];
+            // the link reads A[blk b, blk b-1 .. b]: entries the helper stream's in-panel update of step b-2 wrote (same panel only:
+            // across a panel boundary they come from the outer update, which is on this stream)
+            if (!first && k0 - 2 * GP_NB >= K0) (void)hipStreamWaitEvent(s, ctx->chol_ev[2 * (b - 2) + 1], 0);
+            gp_prof_begin(ctx, GP_PROF_POTRF_DIAG);
+            if (first) gpk_potrf_diag128(s, Akk, lda, dk, info, k0, gp_batch());
+            else gpk_potrf_link128(s, Akk, lda, dk, info, k0, ctx->d_cflags + b, token);
+            gp_prof_end(ctx, GP_PROF_POTRF_DIAG, (double)GP_NB * GP_NB * GP_NB / 3.0 + (first ? 0.0 : 3.0 * GP_NB * GP_NB * GP_NB));
+            (void)hipEventRecord(ev_fac, s);
+            if (!first) {
+                // helper stream: in-panel update of step b-1 -- rows from block b on, columns block b .. panel end, minus block b's own
+                // diagonal block (this step's kernel owns it) -- once this step's kernel has announced its rows of block column b-1
+                const int M = rows - k0, wc = pe - k0;
+                const double *P = A + (size_t)k0 + (size_t)(k0 - GP_NB) * lda;
+                gpk_chol_wait_flag(sA, ctx->d_cflags + b, token, info);
+                gp_prof_begin(ctx, GP_PROF_PANEL_UPD, sA);
+                gpk_gemm_k128_sub(sA, M, wc, P, lda, P, lda, A + (size_t)k0 + (size_t)k0 * lda, lda, 1, GP_NB, GP_NB);
+                gp_prof_end(ctx, GP_PROF_PANEL_UPD, trapezoid_flops(M, wc, GP_NB) - 2.0 * GP_NB * GP_NB * GP_NB, sA);
+                (void)hipEventRecord(ctx->chol_ev[2 * (b - 1) + 1], sA);
+            }
+            // helper stream: panel solve of step b for the rows below block b+1 (block b+1's own rows are its kernel's link; the last
+            // step of a panel has no successor with a link, so it solves everything below)
+            const int r = rows - (k0 + GP_NB), skip = last ? 0 : GP_NB;
+            if (r - skip > 0) {
+                (void)hipStreamWaitEvent(sA, ev_fac, 0);
+                gp_prof_begin(ctx, GP_PROF_TRSM, sA);
+                gpk_trsm_panel128(sA, Akk + GP_NB + skip, r - skip, lda, Akk, lda, dk, nullptr, nullptr, nullptr, gp_batch());
+                gp_prof_end(ctx, GP_PROF_TRSM, (double)(r - skip) * GP_NB * GP_NB, sA);
+            }
+            (void)ev_side;
+        }
+        const int c1 = pe, R = np - c1;
+        if (R <= 0) break;
+        // the panel is complete when the helper stream has finished its last solve (its updates come before that in stream order)
+        (void)hipEventRecord(ev_join, sA);
+        (void)hipStreamWaitEvent(s, ev_join, 0);
+        if (side_busy) { (void)hipStreamWaitEvent(s, ctx->ev_b, 0); side_busy = false; }
+        const double *P = A + (size_t)c1 + (size_t)K0 * lda;
+        const int nnext = lookahead ? std::min(OUTER, R) : R;
+        if (R > nnext) {
+            (void)hipEventRecord(ctx->ev_a, s);
+            (void)hipStreamWaitEvent(sF, ctx->ev_a, 0);
+            const int c2 = c1 + nnext;
+            const double *P2 = A + (size_t)c2 + (size_t)K0 * lda;
+            gp_prof_begin(ctx, GP_PROF_SYRK, sF);
+            gpk_gemm_nt(sF, rows - c2, np - c2, wcols, -1.0, P2, lda, P2, lda, 1.0, A + (size_t)c2 + (size_t)c2 * lda, lda, 1);
+            gp_prof_end(ctx, GP_PROF_SYRK, trapezoid_flops(rows - c2, np - c2, wcols), sF);
+            (void)hipEventRecord(ctx->ev_b, sF);
+            side_busy = true;
+        }
+        gp_prof_begin(ctx, GP_PROF_SYRK);
+        const double tiles128 = trapezoid_flops(rows - c1, nnext, wcols) / (2.0 * GP_NB * GP_NB * wcols);
+        if (tiles128 < small_update_tiles() && small_panel_update())
+            gpk_gemm_k128_sub(s, rows - c1, nnext, P, lda, P, lda, A + (size_t)c1 + (size_t)c1 * lda, lda, 1, wcols);
+        else
+            gpk_gemm_nt(s, rows - c1, nnext, wcols, -1.0, P, lda, P, lda, 1.0, A + (size_t)c1 + (size_t)c1 * lda, lda, 1);
+        gp_prof_end(ctx, GP_PROF_SYRK, trapezoid_flops(rows - c1, nnext, wcols));
+    }
+    // everything the helper streams still hold is ordered before whatever the main stream does next
+    (void)hipEventRecord(ev_join, sA);
+    (void)hipStreamWaitEvent(s, ev_join, 0);
+    if (side_busy) (void)hipStreamWaitEvent(s, ctx->ev_b, 0);
+}
+
 void chol_blocked(gp_ctx *ctx, double *A, int np, int lda, double *dinv, int extra, int count = 1, size_t strideA = 0, size_t strideDinv = 0,
                   int *info = nullptr) {
     hipStream_t s = ctx->stream, s2 = ctx->side;
@@ -129,6 +240,19 @@ void chol_blocked(gp_ctx *ctx, double *A, int np, int lda, double *dinv, int ext
     // outer panel width: 512 (K = 512 trailing updates); 1024 measured 3 % faster at n = 32768 (205 -> 198.5 ms), equal at 8192
     const int outer_env = gp_env_blocks("GPCORE_OUTER");
     const int OUTER = outer_env ? outer_env : (np > 16384 ? 2 * GP_OUTER : GP_OUTER);
+    {   // GPCORE_CHOL_FUSED = 1: one launch per step on the diagonal chain (chol_fused).  OFF by default: measured slower at every size
+        // (refit ms three-launch chain / fused: n = 4096 1.99 / 2.23, n = 8192 6.01 / 6.35, n = 12288 14.41 / 15.04, n = 16384 30.2 /
+        // 30.6; profiles/r03_q_fit_fused.log).  The link's 128-row solve and 36-tile update are 4.7 MFLOP that ONE CU's matrix pipes
+        // take ~20 us over (EP's chain kernel pays the same, profiles/r03_i_block2_stamps.txt) -- as long as the panel solve and the
+        // in-panel update they replace take on the whole chip (13.8 + 22.4 us), and the helper stream's update, which can only
+        // start at the flag, now sits between two steps.  Read per call so that a test can run both forms in one process.
+        const char *fe = getenv("GPCORE_CHOL_FUSED");
+        const bool want = fe && atoi(fe) != 0;
+        if (want && count == 1 && info == ctx->d_info && np >= 2 * GP_NB && ctx->side2 && chol_fused_reserve(ctx, np / GP_NB)) {
+            chol_fused(ctx, A, np, lda, dinv, extra, OUTER, lookahead);
+            return;
+        }
+    }
     for (int K0 = 0; K0 < np; K0 += OUTER) {
         const int wcols = std::min(OUTER, np - K0);
         for (int k0 = K0; k0 < K0 + wcols; k0 += GP_NB) {

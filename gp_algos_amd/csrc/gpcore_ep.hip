@@ -906,6 +906,10 @@ __global__ void ep_wait_flag_kernel(const int *__restrict__ flags, int stride, i
     const int *f = flags + (size_t)blockIdx.x * stride;
     int it = 0;
     while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != token) {
+        // once a wait of this sweep has timed out the result is lost anyway: the later ones fall through at once, so that a
+        // run under a tool that serialises kernels (rocprofv3 --pmc: producer and waiter never run side by side) ends in
+        // seconds with GP_EHIP instead of crawling through one time-out per block
+        if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
         if (++it > 200000) { atomicExch(err, 1 + (int)blockIdx.x); break; }
         __builtin_amdgcn_s_sleep(32);
     }

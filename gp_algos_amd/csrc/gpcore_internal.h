@@ -47,6 +47,10 @@ struct gp_ctx {
     // scratch reused across calls
     double *d_scalars = nullptr;  // small device scratch (256 doubles)
     int *d_info = nullptr;        // device-side failing-pivot flag
+    // fused diagonal chain of single factorisations (chol_blocked): per-step flags + error word, per-step events, token
+    int *d_cflags = nullptr;
+    int cflags_cap = 0, chol_epoch = 0;
+    std::vector<hipEvent_t> chol_ev;
 };
 
 struct gp_model {
@@ -102,7 +106,8 @@ void gpk_gemm_nt(hipStream_t s, int M, int N, int K, double alpha, const double 
                  const double *Cin = nullptr, int ldcin = 0);   // beta term read from Cin instead of C (C = beta*Cin + alpha*A*B^T; batch stride bt.s3)
 // C (M x N; lower != 0: the lower trapezoid, i >= j on its diagonal tiles) -= A (M x 128) B (N x 128)^T (K a multiple of 32) on 64 x 64 tiles: the
 // latency-bound updates of a single factorisation -- few 128 x 128 tiles, short K (M, N multiples of 64)
-void gpk_gemm_k128_sub(hipStream_t s, int M, int N, const double *A, int lda, const double *B, int ldb, double *C, int ldc, int lower, int K = 128);
+void gpk_gemm_k128_sub(hipStream_t s, int M, int N, const double *A, int lda, const double *B, int ldb, double *C, int ldc, int lower, int K = 128,
+                       int skip_rows = 0);   // tiles whose first row is < skip_rows are left alone
 // C[M x 128] = A[M x K] * B[128 x K]^T with fused row reductions (sumsq[m] += sum_n C(m,n)^2, dots[m] += sum_n C(m,n) tvec[n]);
 // C may be the last 128 columns of A (in-place posterior step).
 void gpk_gemm_nt_rowred(hipStream_t s, int M, int N, int K, const double *A, int lda, const double *B, int ldb, double *C, int ldc,
@@ -149,6 +154,10 @@ int gpk_init_gemm_kernels();
 // MFMA-blocked critical-path kernels (kernels_diag.hip).  dinv holds the inverses of the 16x16 diagonal
 // tiles of L: tile b (rows 16b..16b+15) at dinv + 256*b, element (c,k) at c + 16k; a 128-block owns 8 tiles.
 void gpk_potrf_diag128(hipStream_t s, double *A, int lda, double *dinv_k, int *d_info, int base, gp_batch bt = gp_batch());   // strides: A, dinv; d_info + 1 per problem
+// the same with the link to the step before as its prologue (A = block (k, k), k >= 1: solves A[blk k, blk k-1] against the previous
+// diagonal block in place, applies it to the block, sets *flag = token when the solved rows are in memory), and the bounded wait
+void gpk_potrf_link128(hipStream_t s, double *A, int lda, double *dinv_k, int *d_info, int base, int *flag, int token);
+void gpk_chol_wait_flag(hipStream_t s, const int *flag, int token, int *err);
 // optional fused row reductions: sumsq[p] += sum_c X(p,c)^2 ; dots[p] += sum_c X(p,c) tvec[c]
 // EP: the 128 rows of the delayed columns that belong to the next site block (X <- X Lmat^-T in place, X2 = X diag(cs2), dots += X tvec)
 // and the 128 x 128 lower tile D -= X2 X^T the next block kernel reads, one workgroup (kernels_diag.hip)

@@ -379,7 +379,7 @@ __global__ __launch_bounds__(WV * 64, 1) void gemm_fused_kernel(int M, int N, in
 constexpr int SK_T = 64, SK_S = 80, SK_C = 32;
 template <int LOWER>
 __global__ __launch_bounds__(256) void gemm_k128_kernel(int M, int N, int K, const double *__restrict__ A, int lda, const double *__restrict__ B,
-                                                        int ldb, double *__restrict__ C, int ldc) {
+                                                        int ldb, double *__restrict__ C, int ldc, int skip_rows) {
     __shared__ __attribute__((aligned(16))) double as[SK_C * SK_S], bs[SK_C * SK_S];
     int bi, bj;
     const int tm = M / SK_T;
@@ -394,6 +394,7 @@ __global__ __launch_bounds__(256) void gemm_k128_kernel(int M, int N, int K, con
     }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fk = lane >> 4;
     const int i0 = bi * SK_T, j0 = bj * SK_T, wi = (wave & 1) * 32, wj = (wave >> 1) * 32;
+    if (i0 < skip_rows) return;      // rows somebody else owns (the fused Cholesky chain: the next diagonal block is its kernel's business)
     const double *Ap = A + i0 + lane + (size_t)wave * lda, *Bp = B + j0 + lane + (size_t)wave * ldb;   // thread: row `lane`, k = wave + 4 q
     double ra[SK_C / 4], rb[SK_C / 4];
 #pragma unroll
@@ -566,11 +567,12 @@ small_tiles:
 }
 
 // C (M x N, lower trapezoid if `lower`) -= A (M x 128) B (N x 128)^T; M, N multiples of 64
-void gpk_gemm_k128_sub(hipStream_t s, int M, int N, const double *A, int lda, const double *B, int ldb, double *C, int ldc, int lower, int K) {
+void gpk_gemm_k128_sub(hipStream_t s, int M, int N, const double *A, int lda, const double *B, int ldb, double *C, int ldc, int lower, int K,
+                       int skip_rows) {
     if (M <= 0 || N <= 0 || K <= 0) return;
     const int tm = M / SK_T, tn = N / SK_T;
-    if (lower) hipLaunchKernelGGL(gemm_k128_kernel<1>, dim3(tn * tm - tn * (tn - 1) / 2), dim3(256), 0, s, M, N, K, A, lda, B, ldb, C, ldc);
-    else hipLaunchKernelGGL(gemm_k128_kernel<0>, dim3(tm * tn), dim3(256), 0, s, M, N, K, A, lda, B, ldb, C, ldc);
+    if (lower) hipLaunchKernelGGL(gemm_k128_kernel<1>, dim3(tn * tm - tn * (tn - 1) / 2), dim3(256), 0, s, M, N, K, A, lda, B, ldb, C, ldc, skip_rows);
+    else hipLaunchKernelGGL(gemm_k128_kernel<0>, dim3(tm * tn), dim3(256), 0, s, M, N, K, A, lda, B, ldb, C, ldc, skip_rows);
 }
 
 double gpk_probe_mfma(hipStream_t s, int num_cu, int waves_per_simd, double *clock_mhz, double *cycles_per_mfma) {

@@ -28,7 +28,9 @@ python3 $R/bench.py --workload c4 --steps 2 > $O/bench_c4.json 2> $O/bench_c4.er
 python3 $R/bench.py --workload c5 --steps 1 --warmup 1 > $O/bench_c5.json 2> $O/bench_c5.err && say "c5 ok"
 pmc c2 --steps 1 --warmup 1 --no-cpu-baseline --no-c3
 pmc c3 --workload c3 --steps 1 --warmup 1
-pmc c4 --workload c4 --steps 1
+# (c4: the fused chain kernel announces its solved rows to a kernel that waits on the side stream; under --pmc the profiler runs one
+#  kernel at a time, so the waiter would only ever time out -- the counters are taken on the two-launch form, same GEMM kernels)
+GPCORE_EP_FUSED=0 pmc c4 --workload c4 --steps 1
 pmc c5 --workload c5 --steps 1 --warmup 1 --test-points 262144
 [ -n "$QUICK" ] && exit 0
 rocprofv3 --kernel-trace -d $O/trace_c4 -o c4 -- python3 $R/tools/ep_sweeps.py 4096 30 > $O/trace_c4.log 2>&1 && say "c4 trace ok"
