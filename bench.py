@@ -255,6 +255,11 @@ def run_secondary(args):
         dt = gdist.max_over_ranks(t_rank, device=coll_dev)
         times = gdist.all_gather_rows(np.array([[t_rank]]), world, device=coll_dev) if world > 1 else np.array([[t_rank]])
         roof = _roofline_from_profile(ctx, L, (L.GP_PROF_GEMM, L.GP_PROF_SYRK), names, "c5")
+        if roof:
+            # posterior step i multiplies the m_b x 128 (i + 1) prefix of Vt by a 128 x 128 (i + 1) block row of Lw: averaged over the
+            # n / 128 steps of a full batch (the PMC passes ran full batches of 131072 rows)
+            mb = min(m, 131072)
+            roof["algorithmic_bytes_per_launch"] = 8.0 * (mb * ((n + 128) / 2.0) + 128 * ((n + 128) / 2.0) + mb * 128)
         if rank == 0:
             var = full[:, 1]
             print(json.dumps({"metric": "posterior variances/sec at n=%d fp64 (L resident)" % n, "value": m_total * args.steps / dt,
@@ -279,18 +284,41 @@ def run_secondary(args):
         ep = EpClassifierState(ctx, K, p["y"])
         ep.sweep(1)
         fence()
-        ctx.profile(prof_mask)
         t0 = time.perf_counter()
         for _ in range(args.steps):
             tau, nu = ep.sweep(sweeps)
         fence()
         dt = gdist.max_over_ranks(time.perf_counter() - t0, device=coll_dev)
+        # the roofline block's HIP events (two per launch of the profiled classes, on four streams) cost this latency-bound workload
+        # ~5 %: they are taken on ONE extra step after the timed ones
+        ctx.profile(prof_mask)
+        ep.sweep(sweeps)
+        fence()
         ctx.profile(0)
         names_c4 = dict(names)
         names_c4[L.GP_PROF_SYRK] = ("gemm_nt_f64_kernel<1,*> / gemm_k128_kernel<1> (lower-trapezoid products of the refactorisation that runs under "
                                     "the site loop: K = 512 trailing updates, next covariance -= Vt Vt^T; launched on two side streams, so a "
                                     "launch shares the chip with up to three other streams and its duration includes that sharing)")
         roof = _roofline_from_profile(ctx, L, (L.GP_PROF_GEMM, L.GP_PROF_SYRK, L.GP_PROF_PANEL_UPD), names_c4, "c4")
+        # the same EP run over a GRID of settings (MeshHyperParamsLogLikelihoodEvaluator.scala:26-40): 12 settings x 10 sweeps, in lockstep
+        # (gp_ep_lml_rbf_batched's default) and one setting at a time; outside the timed region, every rank its own copy
+        grid = None
+        if not args.no_c3:
+            th = p["theta"]
+            thetas = np.stack([th * np.concatenate(([1.0 + 0.05 * b], np.ones(th.size - 2) * (1.0 + 0.03 * b), [1.0])) for b in range(12)])
+            ctx.ep_lml_rbf_batched(p["X"], p["y"], thetas[:3], stop_eps=-1.0, max_sweeps=2)
+            t1 = time.perf_counter()
+            gl, _, _ = ctx.ep_lml_rbf_batched(p["X"], p["y"], thetas, stop_eps=-1.0, max_sweeps=10)
+            t_lock = time.perf_counter() - t1
+            os.environ["GPCORE_EP_LOCKSTEP"] = "0"
+            t1 = time.perf_counter()
+            gs, _, _ = ctx.ep_lml_rbf_batched(p["X"], p["y"], thetas, stop_eps=-1.0, max_sweeps=10)
+            t_ser = time.perf_counter() - t1
+            del os.environ["GPCORE_EP_LOCKSTEP"]
+            grid = {"settings": 12, "sweeps_each": 10, "lockstep_sweeps_per_s": 120 / t_lock, "one_at_a_time_sweeps_per_s": 120 / t_ser,
+                    "lockstep_executed_tflops": (8.0 / 3.0) * float(n) ** 3 * 120 / t_lock / 1e12,
+                    # (the batch takes the next covariance in K = 1024 steps, a single run in K = 256: same sums, grouped differently)
+                    "max_rel_diff_lml": float(np.max(np.abs(gl - gs) / np.abs(gs)))}
         if rank == 0:
             tf = (13.0 / 3.0) * float(n) ** 3 * sweeps * args.steps / dt / 1e12    # 4 1/3 n^3 per sweep
             tf_exec = (8.0 / 3.0) * float(n) ** 3 * sweeps * args.steps / dt / 1e12
@@ -308,7 +336,7 @@ def run_secondary(args):
                                                     "lockstep instead (gp_ep_lml_rbf_batched: profiles/*ep_mesh_perf*)",
                               "executed_flops_note": "the sweep executes 2 2/3 n^3 (trailing-only rank-128 updates n^3/3, Cholesky n^3/3, "
                                                      "V n^3, Sigma n^3), the 4 1/3 n^3 of SURVEY 8(d) counts full-square rank-1 updates",
-                              "roofline": roof,
+                              "roofline": roof, "ep_grid": grid,
                               "ep_lml_strict": ep.lml(True), "ep_lml_corrected": ep.lml(False),
                               "tau_range": [float(tau.min()), float(tau.max())]}), flush=True)
         ep.close()
