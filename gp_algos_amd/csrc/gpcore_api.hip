@@ -609,7 +609,9 @@ gp_status gpi_ctx_ep_streams(gp_ctx *ctx) {
     // side3 carries its long GEMMs (far trailing updates, next covariance); GPCORE_RESERVED_CUS_EP (default 96 = 12 per XCD)
     // CUs are kept free of them, or the site loop's side stream -- whose work the serial chain waits for one block later --
     // is starved whenever they run (n = 4096 sweeps/s with 32 / 64 / 96 / 128 reserved: 161.3 / 171.3 / 177.2 / 163.9).
-    int reserved_ep = reserved > 0 ? 96 : 0;
+    // (round 3, with the fused chain kernel and the urgent tiles the chain needs less shelter: 40 / 48 / 56 / 64 / 72 / 80 / 96 reserved:
+    // 196.6 / 196.4 / 200.7 / 201.8 / 192.4 / 189.6 / 188 sweeps/s at n = 4096, n = 8192 32.4 at 64 against 29.1 at 96 -> 64)
+    int reserved_ep = reserved > 0 ? 64 : 0;
     if (const char *rc = getenv("GPCORE_RESERVED_CUS_EP")) reserved_ep = atoi(rc);
     // side2 carries the factorisation chain: its workgroups are short-lived (quarter-size tiles) but its single-workgroup
     // diagonal kernel needs a whole CU's LDS, which it only finds quickly on the CUs the masked streams leave alone -- so side2

@@ -47,6 +47,8 @@ struct gp_ep {
     hipEvent_t ev_w = nullptr, ev_pipe = nullptr;   // streamed refactorisation: sweep start on the main stream | its last launch
     int *flags = nullptr;         // np/128 device flags (+ 1 error word): "solved rows of block b are in memory" (ep_block2_kernel -> side stream)
     int epoch = 0;                // token of the current sweep's flags; never reset, so a stale flag cannot match
+    int *uflags = nullptr;        // np/128 counters: urgent tiles of block b's trailing update stored (two per sweep; gpk_gemm_nt -> ep_block2_kernel)
+    int uepoch = 0;               // sweeps that counted so far: block b's counter stands at 2 * uepoch when its tiles of this sweep are in
     bool owns = true;             // false: a view into an ep_slab (problem g of a lockstep batch); the slab's first problem owns the memory
     bool side_pending = false;    // the side stream still owes the second part of Sigma / mu
     bool sig_mirrored = false;    // the strict upper triangle of Sig mirrors the lower one (only gp_ep_get needs it)
@@ -641,7 +643,8 @@ __global__ __launch_bounds__(64 * EP_BLOCK1_WAVES) void ep_block2_kernel(int n, 
                                                                         double *__restrict__ vec, const int *__restrict__ y,
                                                                         double *__restrict__ blk, double *__restrict__ cvbase,
                                                                         double *__restrict__ Scbase, int *__restrict__ flags, int par,
-                                                                        int token, ep_strides es, int scoff) {
+                                                                        int token, ep_strides es, int scoff, const int *__restrict__ uwait,
+                                                                        int utarget, int *__restrict__ uerr) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     constexpr int LS = GP_NB + 1;
     Sig += (size_t)blockIdx.x * es.sig, vec += (size_t)blockIdx.x * es.vec, y += (size_t)blockIdx.x * es.y;
@@ -674,6 +677,21 @@ __global__ __launch_bounds__(64 * EP_BLOCK1_WAVES) void ep_block2_kernel(int n, 
         yb[r] = live ? (double)y[i0 + r] : 0.0;
     }
     if constexpr (PRO) {
+        if (uwait) {
+            // The two tiles of Sigma this prologue reads were updated by the side stream's trailing update of block b-2, which
+            // announces them with a counter as soon as they are stored (gpk_gemm_nt's urgent tiles) -- this kernel was launched
+            // without waiting for that whole update.  Bounded: the update was enqueued before this kernel and depends on nothing
+            // after it; ~0.3 s without the count means something else is wrong, recorded in *uerr (the sweep returns GP_EHIP).
+            if (tid == 0) {
+                int it = 0;
+                while (__hip_atomic_load(uwait, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < utarget) {
+                    if (__hip_atomic_load(uerr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                    if (++it > 1000000) { atomicExch(uerr, 1000 + i0 / GP_NB); break; }
+                    __builtin_amdgcn_s_sleep(8);
+                }
+            }
+            __syncthreads();
+        }
         const double *pL = blk + (size_t)(1 - par) * EP_BLK_ELEMS, *pdinv = pL + GP_NB * GP_NB;     // the block before: unit-lower factor,
         const double *pc = cvbase + (size_t)(1 - par) * 2 * GP_NB;                                  //   its tile inverses, c and coef
         double *X = Sig + i0 + (size_t)(i0 - GP_NB) * np;      // rows of this block, columns of the block before (solved in place)
@@ -1224,6 +1242,8 @@ gp_status ep_alloc(gp_ctx *ctx, int n, const int32_t *y, gp_ep **out, int G = 1)
     if (e == hipSuccess) e = hipMalloc(&ep->flags, (size_t)G * (np / GP_NB + 1) * sizeof(int));
     hipStream_t s = ctx->stream;
     if (e == hipSuccess) e = hipMemsetAsync(ep->flags, 0, (size_t)G * (np / GP_NB + 1) * sizeof(int), s);
+    if (e == hipSuccess) e = hipMalloc(&ep->uflags, (np / GP_NB + 1) * sizeof(int));
+    if (e == hipSuccess) e = hipMemsetAsync(ep->uflags, 0, (np / GP_NB + 1) * sizeof(int), s);
     if (e == hipSuccess) e = hipMemsetAsync(ep->K, 0, nn, s);
     if (e == hipSuccess) e = hipMemsetAsync(ep->L, 0, 2 * nn, s);
     if (e == hipSuccess) e = hipMemsetAsync(ep->y, 0, np * sizeof(int), s);
@@ -1255,7 +1275,7 @@ gp_status ep_start(gp_ep *ep) {
 // everything to the right of nl: a quarter of the read-modify-write traffic on those columns and a GEMM shape (K = 512) that runs at
 // twice the rate of K = 128.  Sc holds the panel's scaled columns side by side (block pb in column block pb % 4), S is in place in
 // Sigma's dead column panels.  bt: lockstep batch (strides A = Sc, B = C = Sigma).
-void ep_trailing_update(gp_ctx *ctx, hipStream_t st, int np, int i0, bool two, double *Sc, double *Sig, gp_batch bt) {
+void ep_trailing_update(gp_ctx *ctx, hipStream_t st, int np, int i0, bool two, double *Sc, double *Sig, gp_batch bt, int *uflag = nullptr) {
     const int pb = i0 / GP_NB - 1, jb = pb % (EP_OUTER / GP_NB);
     const int P0 = pb / (EP_OUTER / GP_NB) * EP_OUTER, pe = std::min(np, P0 + EP_OUTER);
     const int nl = two ? std::min(np, pe + GP_NB) : np;
@@ -1264,7 +1284,7 @@ void ep_trailing_update(gp_ctx *ctx, hipStream_t st, int np, int i0, bool two, d
     const double tiles = (double)(N / GP_NB) * (M / GP_NB) - (double)(N / GP_NB) * (N / GP_NB - 1) / 2.0;
     gp_prof_begin(ctx, GP_PROF_GEMM, st);
     gpk_gemm_nt(st, M, N, GP_NB, -1.0, Sc + (size_t)jb * GP_NB * np + i0, np, Sig + (size_t)i0 + (size_t)(i0 - GP_NB) * np, np, 1.0,
-                Sig + (size_t)i0 + (size_t)i0 * np, np, 1, 0, bt);
+                Sig + (size_t)i0 + (size_t)i0 * np, np, 1, 0, bt, nullptr, 0, uflag);
     gp_prof_end(ctx, GP_PROF_GEMM, bt.count * tiles * 2.0 * GP_NB * GP_NB * GP_NB, st);
     if (two && i0 == pe && nl < np) {
         const int R = np - nl, Kp = pe - P0;
@@ -1339,7 +1359,13 @@ gp_status ep_sweep_lockstep(ep_slab &sl, int count) {
     gp_ctx *ctx = sl.ctx;
     GP_TRY(gpi_ctx_ep_streams(ctx));
     gp_ep *e0 = sl.ep[0];
-    hipStream_t s = ctx->stream, s2 = ctx->side, s3 = ctx->side2, s4 = ctx->side3;
+    // The fourth stream is CU-masked for the single run's sake (64 CUs kept free of its long GEMMs so that the chain's small kernels
+    // find a CU); a batch is bound by GEMM throughput instead and loses by the mask (12 problems at n = 4096, aggregate sweeps/s with
+    // 0 / 32 / 64 / 96 CUs reserved: 289 / 281 / 271 / 245), so its long GEMMs go to the unmasked third stream behind the factorisation
+    // chain from np = 4096 on (n = 4096: 287.6 against 272.1 sweeps/s aggregate; n = 8192: 39.8 either way; below that the fourth stream
+    // pays: n = 2048 1669 against 1559).  GPCORE_EP_LOCK_S4 = 0 / 1 forces.
+    const bool own_s4 = [np = sl.np] { const char *e = getenv("GPCORE_EP_LOCK_S4"); return e ? atoi(e) != 0 : np < 4096; }();
+    hipStream_t s = ctx->stream, s2 = ctx->side, s3 = ctx->side2, s4 = own_s4 ? ctx->side3 : ctx->side2;
     const int n = sl.n, np = sl.np, nblk = np / GP_NB, ldl = e0->ldl;
     // columns of Vt per next-covariance update: a batch is bound by GEMM throughput, not by the chain, so long updates pay (n = 4096,
     // 12 problems, K = 256 / 512 / 1024: 229 / 239 / 244 sweeps/s aggregate)
@@ -1373,10 +1399,10 @@ gp_status ep_sweep_lockstep(ep_slab &sl, int count) {
         if (b >= 2) GP_HIP(ctx, hipStreamWaitEvent(s, e0->ev[4 * (b - 2) + 2], 0));
         if (b > 0)
             hipLaunchKernelGGL(ep_block2_kernel<true>, dim3(count), dim3(64 * EP_BLOCK1_WAVES), EP_BLOCK2_LDS, s, n, np, i0, bsz, e0->Sig, e0->vec, e0->y,
-                               e0->blk, e0->cvec, e0->Sc, e0->flags, par, token, es, ((b - 1) % (EP_OUTER / GP_NB)) * GP_NB * np);
+                               e0->blk, e0->cvec, e0->Sc, e0->flags, par, token, es, ((b - 1) % (EP_OUTER / GP_NB)) * GP_NB * np, nullptr, 0, nullptr);
         else
             hipLaunchKernelGGL(ep_block2_kernel<false>, dim3(count), dim3(64 * EP_BLOCK1_WAVES), EP_BLOCK2_LDS, s, n, np, i0, bsz, e0->Sig, e0->vec, e0->y,
-                               e0->blk, e0->cvec, e0->Sc, e0->flags, par, token, es, 0);
+                               e0->blk, e0->cvec, e0->Sc, e0->flags, par, token, es, 0, nullptr, 0, nullptr);
         hipEvent_t ev_fac = e0->ev[4 * b], ev_vt = e0->ev[4 * b + 3];
         GP_HIP(ctx, hipEventRecord(ev_fac, s));
         // refactorisation under the site loop, one block behind it (third and fourth stream)
@@ -1386,7 +1412,7 @@ gp_status ep_sweep_lockstep(ep_slab &sl, int count) {
             hipLaunchKernelGGL(ep_wscale_kernel, dim3(gx, GP_NB + std::min((i0 / 2 + gx - 1) / gx, 256), count), dim3(256), 0, s3, e0->L, ldl, np, i0,
                                e0->tau(), n, e0->st(), sl.sL(), sl.sVec());
         }
-        gpi_chol_panel_step(ctx, s3, e0->L, np, ldl, e0->dinv, np, i0, ev_vt, far_split ? s4 : nullptr, e0->ev_parta, count, sl.sL(), sl.sDinv(), sl.info);
+        gpi_chol_panel_step(ctx, s3, e0->L, np, ldl, e0->dinv, np, i0, ev_vt, (far_split && own_s4) ? s4 : nullptr, e0->ev_parta, count, sl.sL(), sl.sDinv(), sl.info);
         if ((b + 1) % sig_blocks == 0 || b >= nblk - 2) {
             GP_HIP(ctx, hipStreamWaitEvent(s4, ev_vt, 0));
             const int kw = i0 + GP_NB - pend0;
@@ -1475,6 +1501,9 @@ gp_status gp_ep_sweep(gp_ep *ep, int nsweeps, double *tau, double *nu, int *info
     const bool two = fused && [] { const char *e = getenv("GPCORE_EP_TWOLEVEL"); return e && atoi(e) != 0; }();
     int *flag_err = ep->flags + np / GP_NB;
     if (fused) GP_HIP(ctx, hipMemsetAsync(flag_err, 0, sizeof(int), s));
+    // urgent tiles (see the launch of ep_block2_kernel below); not with the two-level updates (their rank-128 part may be narrower than
+    // two tile columns)
+    const bool urgent = fused && !two && [] { const char *e = getenv("GPCORE_EP_URGENT"); return !e || atoi(e) != 0; }();
     const bool far_split = [] { const char *e = getenv("GPCORE_EP_FAR"); return !e || atoi(e) != 0; }();
     // columns of Vt per next-covariance update (GPCORE_EP_SIG_K; n = 4096 sweeps/s at 128 / 256 / 384 / 512 / 1024 / 2048: 173 / 181 / 175 / 177 /
     // 172 / 155 -- short enough to spread the fourth stream's load evenly, long enough for the GEMM)
@@ -1493,6 +1522,7 @@ gp_status gp_ep_sweep(gp_ep *ep, int nsweeps, double *tau, double *nu, int *info
     }
     for (int sw = 0; sw < nsweeps; ++sw) {
         const int token = ++ep->epoch;
+        const int utarget = urgent ? ++ep->uepoch : 0;
         // Only the TRAILING part of the recurrence is carried: the sites after a block read mu_i and Sigma_ii "as of now",
         // which depend on the earlier blocks through rows/columns >= their own block only, and the end-of-sweep
         // refactorisation (:56-61) rebuilds Sigma and mu from the site parameters anyway.  So the delayed columns
@@ -1530,14 +1560,20 @@ gp_status gp_ep_sweep(gp_ep *ep, int nsweeps, double *tau, double *nu, int *info
             double *Lmat = ep->blk + (size_t)par * (GP_NB * GP_NB + 8 * 256), *bdinv = Lmat + GP_NB * GP_NB;
             double *cvec = ep->cvec + (size_t)par * 2 * GP_NB, *ncoef = cvec + GP_NB;   // c and coef of every site of the block
             if (fused) {
-                // the prologue reads Sigma[blk b, blk b-1 .. b]: entries the side stream's update of block b-2 wrote
-                if (b >= 2) GP_HIP(ctx, hipStreamWaitEvent(s, ep->ev[4 * (b - 2) + 2], 0));
+                // the prologue reads Sigma[blk b, blk b-1 .. b]: entries the side stream's update of block b-2 wrote.  With urgent tiles
+                // (GPCORE_EP_URGENT, default) the kernel is launched WITHOUT waiting for that launch to finish: the update announces those
+                // two tiles with a counter the moment they are stored, and the prologue waits for the counter (bounded).  The chain then
+                // never waits for the rest of a 500-tile update it does not read -- the block periods of 200-260 us in the first half of
+                // a sweep (profiles/r03_j_c4_sweep_summary.txt) were exactly that.
+                const bool uw = urgent && b >= 2;
+                if (b >= 2 && !uw) GP_HIP(ctx, hipStreamWaitEvent(s, ep->ev[4 * (b - 2) + 2], 0));
                 if (b > 0)
                     hipLaunchKernelGGL(ep_block2_kernel<true>, dim3(1), dim3(64 * EP_BLOCK1_WAVES), EP_BLOCK2_LDS, s, n, np, i0, bsz, ep->Sig, ep->vec,
-                                       ep->y, ep->blk, ep->cvec, ep->Sc, ep->flags, par, token, ep_strides(), ((b - 1) % (EP_OUTER / GP_NB)) * GP_NB * np);
+                                       ep->y, ep->blk, ep->cvec, ep->Sc, ep->flags, par, token, ep_strides(), ((b - 1) % (EP_OUTER / GP_NB)) * GP_NB * np,
+                                       uw ? ep->uflags + (b - 2) : nullptr, 2 * utarget, flag_err);
                 else
                     hipLaunchKernelGGL(ep_block2_kernel<false>, dim3(1), dim3(64 * EP_BLOCK1_WAVES), EP_BLOCK2_LDS, s, n, np, i0, bsz, ep->Sig, ep->vec,
-                                       ep->y, ep->blk, ep->cvec, ep->Sc, ep->flags, par, token, ep_strides(), 0);
+                                       ep->y, ep->blk, ep->cvec, ep->Sc, ep->flags, par, token, ep_strides(), 0, nullptr, 0, nullptr);
             } else if (block1)
                 hipLaunchKernelGGL(ep_block1_kernel, dim3(1), dim3(64 * EP_BLOCK1_WAVES), EP_BLOCK1_LDS, s, n, np, i0, bsz, ep->Sig, ep->mu(), ep->y,
                                    ep->tau(), ep->nu(), ep->cav_tau(), ep->cav_nu(), cvec, ncoef, Lmat, bdinv);
@@ -1578,7 +1614,7 @@ gp_status gp_ep_sweep(gp_ep *ep, int nsweeps, double *tau, double *nu, int *info
                 // (solve, wait, update), not on five.
                 if (np - i0 > GP_NB) {
                     hipLaunchKernelGGL(ep_wait_flag_kernel, dim3(1), dim3(1), 0, s2, ep->flags + b, 0, token, flag_err);
-                    ep_trailing_update(ctx, s2, np, i0, two, ep->Sc, ep->Sig, gp_batch());
+                    ep_trailing_update(ctx, s2, np, i0, two, ep->Sc, ep->Sig, gp_batch(), urgent ? ep->uflags + (b - 1) : nullptr);
                 }
                 GP_HIP(ctx, hipEventRecord(ep->ev[4 * (b - 1) + 2], s2));
                 last_side = ep->ev[4 * (b - 1) + 2];
@@ -2024,7 +2060,7 @@ void gp_ep_destroy(gp_ep *ep) {
     }
     for (hipEvent_t ev : ep->ev) if (ev) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : {ep->ev_chol, ep->ev_parta, ep->ev_partb, ep->ev_w, ep->ev_pipe}) if (ev) (void)hipEventDestroy(ev);
-    void *ptrs[] = {ep->K, ep->Sig, ep->Sig2, ep->L, ep->dinv, ep->S, ep->Sc, ep->blk, ep->vec, ep->cvec, ep->y, ep->flags};
+    void *ptrs[] = {ep->K, ep->Sig, ep->Sig2, ep->L, ep->dinv, ep->S, ep->Sc, ep->blk, ep->vec, ep->cvec, ep->y, ep->flags, ep->uflags};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete ep;
 }

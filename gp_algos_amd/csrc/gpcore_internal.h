@@ -103,7 +103,8 @@ struct gp_batch {
 // ktri != 0: A(i,k) is zero for k < i (upper-triangular operand): each tile starts its k loop at its row block.
 void gpk_gemm_nt(hipStream_t s, int M, int N, int K, double alpha, const double *A, int lda, const double *B, int ldb,
                  double beta, double *C, int ldc, int lower, int ktri = 0, gp_batch bt = gp_batch(),   // strides: A, B, C
-                 const double *Cin = nullptr, int ldcin = 0);   // beta term read from Cin instead of C (C = beta*Cin + alpha*A*B^T; batch stride bt.s3)
+                 const double *Cin = nullptr, int ldcin = 0,    // beta term read from Cin instead of C (C = beta*Cin + alpha*A*B^T; batch stride bt.s3)
+                 int *uflag = nullptr);   // single lower products: *uflag += 1 (release) when tile (1,0) / (1,1) is stored, by two workgroups at the head of the grid
 // C (M x N; lower != 0: the lower trapezoid, i >= j on its diagonal tiles) -= A (M x 128) B (N x 128)^T (K a multiple of 32) on 64 x 64 tiles: the
 // latency-bound updates of a single factorisation -- few 128 x 128 tiles, short K (M, N multiples of 64)
 void gpk_gemm_k128_sub(hipStream_t s, int M, int N, const double *A, int lda, const double *B, int ldb, double *C, int ldc, int lower, int K = 128,

@@ -71,12 +71,13 @@ template <int LOWER, int HAS_BETA, int NW, int RR = 0>
 __global__ __launch_bounds__(NW * 64, NW / 2) void gemm_nt_f64_kernel(int M, int N, int K, double alpha, const double *__restrict__ A, int lda,
                                                            const double *__restrict__ B, int ldb, double beta,
                                                            double *__restrict__ C, int ldc, int ktri, gp_batch bt, gemm_rowred rr,
-                                                           const double *__restrict__ Cin, int ldcin) {
+                                                           const double *__restrict__ Cin, int ldcin, int *__restrict__ uflag) {
     __shared__ __attribute__((aligned(16))) double smem[2 * 2 * TK * LDS_STRIDE];
     double *As = smem;                          // [2][TK][LDS_STRIDE]
     double *Bs = smem + 2 * TK * LDS_STRIDE;    // [2][TK][LDS_STRIDE]
 
     int bi, bj;
+    bool urgent = false;
     int prob = blockIdx.y;   // problem of a lockstep batch (same shapes, operands bt.s* doubles apart); a single problem has gridDim.y == 1
     if (LOWER && ktri) {
         // The k loop of tile row bi runs over K - bi*128, so equal tile COUNTS per XCD would leave the XCD holding the first rows
@@ -94,10 +95,22 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void gemm_nt_f64_kernel(int M, int
         if (bi < 0) return;   // padding workgroups of the XCDs that own fewer tiles
     } else if (LOWER) {
         // XCD-aware: block ids are dealt round-robin over the 8 XCDs; hand each XCD a contiguous run of the order above
-        const int nwg = gridDim.x, id = blockIdx.x;
-        const int q = nwg >> 3, r = nwg & 7, xcd = id & 7;
-        const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
-        tile_coords_lower(swz, M / TM, N / TN, bi, bj);
+        int nwg = gridDim.x, id = blockIdx.x;
+        if (uflag) {
+            // "urgent" tiles (single problems; the EP chain): the two tiles of tile row 1 -- what the next chain kernel reads of this
+            // update -- are computed by two extra workgroups at the head of the grid, which announce them (release, agent scope) as
+            // soon as they are stored; the regular workgroups that own them step aside.  The chain kernel waits for the counter
+            // instead of for the whole launch.
+            nwg -= 2;
+            if (id < 2) { urgent = true; bi = 1; bj = id; }
+            else id -= 2;
+        }
+        if (!urgent) {
+            const int q = nwg >> 3, r = nwg & 7, xcd = id & 7;
+            const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+            tile_coords_lower(swz, M / TM, N / TN, bi, bj);
+            if (uflag && bi == 1) return;
+        }
     } else {
         // XCD-aware: consecutive block ids round-robin over the 8 XCDs; give each XCD a contiguous
         // run of tiles that share the same B panel (bj) so the panel stays in that XCD's L2.
@@ -202,6 +215,14 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void gemm_nt_f64_kernel(int M, int
                     if (rr.dots) rdt[mt] = fma(v, rr.tvec[n], rdt[mt]);
                 }
             }
+        }
+    }
+    if (urgent) {
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's stores are acknowledged
+        __syncthreads();
+        if (tid == 0) {
+            __threadfence();
+            __hip_atomic_fetch_add(uflag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     if (RR) {
@@ -484,8 +505,9 @@ __global__ __launch_bounds__(256) void mfma_probe_kernel(double *out, unsigned l
 }  // namespace
 
 void gpk_gemm_nt(hipStream_t s, int M, int N, int K, double alpha, const double *A, int lda, const double *B, int ldb,
-                 double beta, double *C, int ldc, int lower, int ktri, gp_batch bt, const double *Cin, int ldcin) {
+                 double beta, double *C, int ldc, int lower, int ktri, gp_batch bt, const double *Cin, int ldcin, int *uflag) {
     if (M <= 0 || N <= 0 || bt.count <= 0) return;
+    if (uflag && !(lower && !ktri && bt.count == 1 && M >= 2 * TM && N >= 2 * TN)) uflag = nullptr;   // urgent tiles: single lower products with a tile row 1
     const gemm_rowred rr;
     const bool hb = beta != 0.0;
     // (The 256 x 128 / 16-wave tile of the posterior step was also tried here for the general launches: C3 658-663 vs 668-675
@@ -496,6 +518,7 @@ void gpk_gemm_nt(hipStream_t s, int M, int N, int K, double alpha, const double 
     static const int nw = [] { const char *e = getenv("GPCORE_GEMM_WAVES"); return (e && atoi(e) == 4) ? 4 : 8; }();
     int ntiles = lower ? ((N / TN) * (M / TM) - (N / TN) * ((N / TN) - 1) / 2) : (M / TM) * (N / TN);   // lower: trapezoid, M >= N
     int gy = bt.count;
+    if (uflag) ntiles += 2;
     if (ktri) {
         if (!lower || M != N) return;   // ktri is the square lower product T T^T only
         int most = 0;                   // grid = 8 x (entries of the XCD that owns the most tiles)
@@ -507,7 +530,7 @@ void gpk_gemm_nt(hipStream_t s, int M, int N, int K, double alpha, const double 
         ntiles = 8 * most;
         gy = 1;
     }
-#define GP_LAUNCH(LO, HB, NWV) hipLaunchKernelGGL((gemm_nt_f64_kernel<LO, HB, NWV>), dim3(ntiles, gy), dim3(NWV * 64), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, ktri, bt, rr, Cin, ldcin)
+#define GP_LAUNCH(LO, HB, NWV) hipLaunchKernelGGL((gemm_nt_f64_kernel<LO, HB, NWV>), dim3(ntiles, gy), dim3(NWV * 64), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, ktri, bt, rr, Cin, ldcin, uflag)
     if (nw == 8) {
         if (lower) { if (hb) GP_LAUNCH(1, 1, 8); else GP_LAUNCH(1, 0, 8); }
         else { if (hb) GP_LAUNCH(0, 1, 8); else GP_LAUNCH(0, 0, 8); }
@@ -561,9 +584,9 @@ small_tiles:
     rr.sumsq = sumsq, rr.tvec = tvec, rr.dots = dots;
     const int ntiles = (M / TM) * (N / TN);
     if (nw == 8)
-        hipLaunchKernelGGL((gemm_nt_f64_kernel<0, 0, 8, 1>), dim3(ntiles), dim3(512), 0, s, M, N, K, 1.0, A, lda, B, ldb, 0.0, C, ldc, 0, gp_batch(), rr, nullptr, 0);
+        hipLaunchKernelGGL((gemm_nt_f64_kernel<0, 0, 8, 1>), dim3(ntiles), dim3(512), 0, s, M, N, K, 1.0, A, lda, B, ldb, 0.0, C, ldc, 0, gp_batch(), rr, nullptr, 0, nullptr);
     else
-        hipLaunchKernelGGL((gemm_nt_f64_kernel<0, 0, 4, 1>), dim3(ntiles), dim3(256), 0, s, M, N, K, 1.0, A, lda, B, ldb, 0.0, C, ldc, 0, gp_batch(), rr, nullptr, 0);
+        hipLaunchKernelGGL((gemm_nt_f64_kernel<0, 0, 4, 1>), dim3(ntiles), dim3(256), 0, s, M, N, K, 1.0, A, lda, B, ldb, 0.0, C, ldc, 0, gp_batch(), rr, nullptr, 0, nullptr);
 }
 
 // C (M x N, lower trapezoid if `lower`) -= A (M x 128) B (N x 128)^T; M, N multiples of 64
