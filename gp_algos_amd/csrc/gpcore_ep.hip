@@ -18,6 +18,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <new>
 #include <thread>
@@ -1520,6 +1521,8 @@ gp_status gp_ep_sweep(gp_ep *ep, int nsweeps, double *tau, double *nu, int *info
         }
         GP_TRY(gpi_ws_get(ctx, WS_PARTIAL, sizeof(double) * (size_t)(SYMV_CHUNKS + 1) * np, &partial));
     }
+    const bool host_time = [] { const char *e = getenv("GPCORE_EP_HOSTTIME"); return e && atoi(e) != 0; }();   // lab: host time spent enqueueing the sweeps
+    const auto host_t0 = std::chrono::steady_clock::now();
     for (int sw = 0; sw < nsweeps; ++sw) {
         const int token = ++ep->epoch;
         const int utarget = urgent ? ++ep->uepoch : 0;
@@ -1564,7 +1567,9 @@ gp_status gp_ep_sweep(gp_ep *ep, int nsweeps, double *tau, double *nu, int *info
                 // (GPCORE_EP_URGENT, default) the kernel is launched WITHOUT waiting for that launch to finish: the update announces those
                 // two tiles with a counter the moment they are stored, and the prologue waits for the counter (bounded).  The chain then
                 // never waits for the rest of a 500-tile update it does not read -- the block periods of 200-260 us in the first half of
-                // a sweep (profiles/r03_j_c4_sweep_summary.txt) were exactly that.
+                // a sweep (profiles/r03_j_c4_sweep_summary.txt) were exactly that.  (Computing the two tiles in a kernel of their own ahead
+                // of the update -- 100 one-wave workgroups that need no LDS slot -- was measured too: 190.8 against 197.0 sweeps/s without
+                // any urgent tiles on the same box; one more launch on the side stream costs more than the earlier tiles gain.)
                 const bool uw = urgent && b >= 2;
                 if (b >= 2 && !uw) GP_HIP(ctx, hipStreamWaitEvent(s, ep->ev[4 * (b - 2) + 2], 0));
                 if (b > 0)
@@ -1675,6 +1680,10 @@ gp_status gp_ep_sweep(gp_ep *ep, int nsweeps, double *tau, double *nu, int *info
         ep->sweeps += 1;
     }
     GP_TRY(ep_join_side(ep));
+    if (host_time && nsweeps > 0)   // (n = 4096: 1.6 ms of host time per 5 ms sweep -- the host runs three sweeps ahead of the GPU; not launch-bound)
+        fprintf(stderr, "gp_ep_sweep: %d sweeps enqueued in %.3f ms of host time (%.1f us per sweep)\n", nsweeps,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count(),
+                std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - host_t0).count() / nsweeps);
     int h = 0;
     GP_TRY(gpi_read_info(ctx, &h));
     if (fused) {
