@@ -24,6 +24,7 @@ struct GramParams {
     // 1 = d/d sf (2 sf e), 2 = d/d l_k (sf^2 e (x_k - y_k)^2 l_k^-3, k = dk), 3 = d/d sn (same ? 2 sn : 0)
     int dmode, dk;
     double dcoef;   // 2 sf | sf^2 l_k^-3 | 2 sn
+    double lnsf2;   // ln(sf^2): the unit kernel carries it inside the exponent
 };
 
 __device__ __forceinline__ void tile_lower(int t, int &bi, int &bj) {
@@ -206,6 +207,223 @@ __global__ __launch_bounds__(256) void gram_mfma_kernel(const double *__restrict
     }
 }
 
+// The form used for d <= 14: the WHOLE exponent on the matrix cores, one wave per job, no workgroup barrier, no LDS tile.
+//     z~_i = (z_i, -|z_i|^2 / 2, 1),   z~_j = (z_j, 1, ln sf^2 - |z_j|^2 / 2)   ->   z~_i . z~_j = ln sf^2 - r_ij^2 / 2,   K_ij = exp(.)
+// (z = (x - c) / l as above; d + 2 <= 16 features = KS <= 4 k-steps of v_mfma_f64_16x16x4_f64).  What the earlier forms lost was not
+// arithmetic but the life cycle of a tile (tools/lab/gram_aug_lab.hip, profiles/r03_g_gram_lab.log): a tile's operand loads queue
+// behind the CU's outstanding stores and come back after microseconds (cross-Gram 1.20 ms with them, 0.97 ms with operands made
+// up from indices), and fp64 MFMA and fp64 VALU instructions do not overlap on this chip (exp alone 350 us + MFMA alone 275 us =
+// 638 us together), so every instruction that is not exp or MFMA counts.  Hence:
+//   * a UNIT is 64 rows x 16 columns of a row strip; a wave takes `upw` consecutive units of the strip-major order (lower forms:
+//     strip b has 4 (b + 1) units), keeps the strip's four row operand blocks in registers for all of them, and asks for the NEXT
+//     64-column tile's features before it issues the current tile's 64 stores -- the loads are back when the tile is done;
+//   * operands go from global memory (X is L2-resident) into MFMA layout directly: lane (fr, fk) holds feature 4 ks + fk of point
+//     fr; the norms come from two cross-lane adds; the accumulator IS the exponent (no norm adds, no scaling after exp);
+//   * MFMA operand roles put the ROW index on lane & 15: each store instruction writes 4 full 128-byte lines.  When the mirrored
+//     half is wanted the column points are fed in the order 4 (fr & 3) + (fr >> 2), which leaves each lane with 4 CONSECUTIVE
+//     columns -> the mirror is one 32-byte store per lane and block (no transpose through LDS).
+// Rounding: the error of the exponent is a few ulp of |z|^2 (absolute), so a wave whose strip or tile holds a point with
+// |z|^2 > GRAM_NORM_LIMIT takes that tile through the reference's per-pair sum instead (raw features, lane = row, the same bits as
+// gram_rbf_kernel): relative error of K below 5e-14 on the fast path, the reference's own rounding on the other, whatever the
+// spread of the data.
+// Measured at n = 8192, m = 65536, d = 8 (lab): lower 84 -> 59 us (4.6 TB/s), mirrored 121 -> 110 us, cross 1.17 -> 0.86 ms (5.0 TB/s).
+constexpr double GRAM_NORM_LIMIT = 64.0;
+constexpr int GU_DMAX = 14;
+
+// exp(t) for FINITE t in [-900, 709.7] and nothing else: argument reduction by n = rint(t log2 e) against ln 2 in two pieces, the
+// degree-11 minimax polynomial the device library's exp uses (same coefficients, same order: bit-identical results in range), one
+// ldexp.  No overflow / underflow / NaN selects (5 instructions of 24): the caller's arguments are ln sf^2 - r^2 / 2 with r^2 <= 256
+// on this path and ln sf^2 finite (the launcher sends anything else to the per-pair kernel); ldexp itself flushes 2^-1075 and below.
+__device__ __forceinline__ double exp_bounded(double t) {
+    const double n = __builtin_rint(t * 0x1.71547652b82fep+0);
+    double f = fma(n, -0x1.62e42fefa39efp-1, t);
+    f = fma(n, -0x1.abc9e3b39803fp-56, f);
+    double p = fma(f, 0x1.ade156a5dcb37p-26, 0x1.28af3fca7ab0cp-22);
+    p = fma(f, p, 0x1.71dee623fde64p-19);
+    p = fma(f, p, 0x1.a01997c89e6b0p-16);
+    p = fma(f, p, 0x1.a01a014761f6ep-13);
+    p = fma(f, p, 0x1.6c16c1852b7b0p-10);
+    p = fma(f, p, 0x1.1111111122322p-7);
+    p = fma(f, p, 0x1.55555555502a1p-5);
+    p = fma(f, p, 0x1.5555555555511p-3);
+    p = fma(f, p, 0x1.000000000000bp-1);
+    p = fma(f, p, 1.0);
+    p = fma(f, p, 1.0);
+    return ldexp(p, (int)n);
+}
+// min without the canonicalising v_max the compiler puts in front of fmin (b is uniform)
+__device__ __forceinline__ double min_raw(double a, double b) {
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "s"(b));
+    return r;
+}
+
+template <int KS, int KR, bool ROW>
+__device__ __forceinline__ double unit_operand(const double (&raw)[KR], int d, const double (&cen)[KR], const double (&il)[KR], int fk, double lnsf2,
+                                                double (&z)[KS]) {
+    double part = 0.0;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) z[ks] = 0.0;
+#pragma unroll
+    for (int ks = 0; ks < KR; ++ks) {
+        const double v = (4 * ks + fk < d) ? (raw[ks] - cen[ks]) * il[ks] : 0.0;
+        z[ks] = v;
+        part = fma(v, v, part);
+    }
+    part += __shfl_xor(part, 16);
+    part += __shfl_xor(part, 32);
+    const double hn = ROW ? -0.5 * part : fma(-0.5, part, lnsf2);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int k = 4 * ks + fk;
+        if (k == d) z[ks] = ROW ? hn : 1.0;
+        if (k == d + 1) z[ks] = ROW ? 1.0 : hn;
+    }
+    return part;   // |z|^2 of this lane's point
+}
+
+// MODE 0: cross-Gram (all tiles); 1: symmetric, lower triangle only; 2: symmetric, mirrored
+template <int KS, int KR, int MODE>
+__global__ __launch_bounds__(64) void gram_unit_kernel(const double *__restrict__ Xr, int nr, int ldxr, const double *__restrict__ Xc, int nc, int ldxc,
+                                                       int d, GramParams prm, const double *__restrict__ cenp, int ldcen, double *__restrict__ K,
+                                                       int ldk, int nbc, int upw, long total) {
+    const int lane = threadIdx.x, fr = lane & 15, fk = lane >> 4;
+    long u0 = (long)blockIdx.x * upw;
+    const long u1 = u0 + upw < total ? u0 + upw : total;
+    const int cperm = (MODE == 2) ? 4 * (fr & 3) + (fr >> 2) : fr;
+    double cen[KR], il[KR];
+#pragma unroll
+    for (int ks = 0; ks < KR; ++ks) {
+        const int k = min(4 * ks + fk, d - 1);
+        cen[ks] = cenp[(size_t)k * ldcen];
+        il[ks] = prm.inv_ls[k];
+    }
+    const double lnsf2 = prm.lnsf2, dval = (prm.sf2 + prm.sn2) + prm.extra;
+    constexpr int JS = (MODE == 2) ? 1 : 4;      // column step between a lane's four accumulator registers
+    // lane parts of the store addresses as 32-bit byte offsets (ldk < 2^25, launcher): uniform base + zext(offset) is the scalar-base
+    // form of global_store, no vector address arithmetic per store
+    const unsigned voff = ((unsigned)fr + (unsigned)((MODE == 2) ? 4 * fk : fk) * (unsigned)ldk) * 8u;    // primary store
+    const unsigned moff = ((unsigned)(4 * fk) + (unsigned)fr * (unsigned)ldk) * 8u;                        // mirrored store
+    double zr[4][KS], zc[4][KS], raw[4][KR];
+    while (u0 < u1) {
+        // the strip u0 lies in, and this wave's range [q0, q1) of its 16-column blocks
+        int bi;
+        long ub;
+        if (MODE == 0) {
+            bi = (int)(u0 / (4 * nbc));
+            ub = (long)bi * 4 * nbc;
+        } else {
+            bi = (int)((sqrt(2.0 * (double)u0 + 1.0) - 1.0) * 0.5);
+            while (2L * bi * (bi + 1) > u0) --bi;
+            while (2L * (bi + 1) * (bi + 2) <= u0) ++bi;
+            bi = __builtin_amdgcn_readfirstlane(bi);      // uniform by construction; the sqrt left it in a vector register
+            ub = 2L * bi * (bi + 1);
+        }
+        const int slen = (MODE == 0) ? 4 * nbc : 4 * (bi + 1);
+        const int q0 = (int)(u0 - ub), q1 = (int)((u1 - ub < slen) ? u1 - ub : slen);
+        const int i0 = bi * 64;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const double *xp = Xr + min(i0 + 16 * b + fr, nr - 1);
+#pragma unroll
+            for (int ks = 0; ks < KR; ++ks) raw[b][ks] = xp[(size_t)min(4 * ks + fk, d - 1) * ldxr];
+        }
+        double rmax = 0.0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) rmax = fmax(rmax, unit_operand<KS, KR, true>(raw[b], d, cen, il, fk, 0.0, zr[b]));
+        const bool rowbig = __any(!(rmax <= GRAM_NORM_LIMIT));
+        const int c0 = q0 >> 2, c1 = (q1 + 3) >> 2;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const double *xp = Xc + min(c0 * 64 + 16 * b + cperm, nc - 1);
+#pragma unroll
+            for (int ks = 0; ks < KR; ++ks) raw[b][ks] = xp[(size_t)min(4 * ks + fk, d - 1) * ldxc];
+        }
+        for (int c = c0; c < c1; ++c) {
+            double cmax = 0.0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) cmax = fmax(cmax, unit_operand<KS, KR, false>(raw[b], d, cen, il, fk, lnsf2, zc[b]));
+            if (c + 1 < c1) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const double *xp = Xc + min((c + 1) * 64 + 16 * b + cperm, nc - 1);
+#pragma unroll
+                    for (int ks = 0; ks < KR; ++ks) raw[b][ks] = xp[(size_t)min(4 * ks + fk, d - 1) * ldxc];
+                }
+            }
+            const int j0 = c * 64;
+            const bool diag = MODE && bi == c;
+            const int cbs = max(q0 - 4 * c, 0), cbe = min(q1 - 4 * c, 4);
+            if (rowbig || __any(!(cmax <= GRAM_NORM_LIMIT))) {
+                // per-pair path: the reference's own sum (x_ik - x_jk) l_k^-2 (x_ik - x_jk) from the raw features, lane = row, the column
+                // point's features at a uniform address (bit-identical with gram_rbf_kernel)
+                const int gi = i0 + lane;
+                double xi[4 * KR];
+#pragma unroll
+                for (int k = 0; k < 4 * KR; ++k) xi[k] = (k < d) ? Xr[min(gi, nr - 1) + (size_t)k * ldxr] : 0.0;
+                for (int jl = 16 * cbs; jl < 16 * cbe; ++jl) {
+                    const int gj = j0 + jl;
+                    const double *xc = Xc + min(gj, nc - 1);
+                    double r2 = 0.0;
+#pragma unroll
+                    for (int k = 0; k < 4 * KR; ++k)
+                        if (k < d) {
+                            const double diff = xi[k] - xc[(size_t)k * ldxc];
+                            r2 = fma(diff * prm.inv_ls2[k], diff, r2);
+                        }
+                    double v = prm.sf2 * exp(-0.5 * r2);
+                    if (MODE && gi == gj) v = dval;
+                    if (gi < nr && gj < nc && !(diag && gi < gj)) K[gi + (size_t)gj * ldk] = v;
+                    if (MODE == 2 && gi < nr && gj < nc && (!diag || gi > gj)) K[gj + (size_t)gi * ldk] = v;
+                }
+                continue;
+            }
+            const bool plain = !diag && i0 + 64 <= nr && j0 + 64 <= nc && (MODE != 2 || (ldk & 3) == 0);
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+                if (cb < cbs || cb >= cbe) continue;
+                gram_d4 acc[4];
+#pragma unroll
+                for (int it = 0; it < 4; ++it) acc[it] = (gram_d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) acc[it] = __builtin_amdgcn_mfma_f64_16x16x4f64(zc[cb][ks], zr[it][ks], acc[it], 0, 0, 0);
+                // register r of lane (fr, fk): row i0 + 16 it + fr, column j0 + 16 cb + (MODE 2 ? 4 fk + r : fk + 4 r)
+                char *cbase = reinterpret_cast<char *>(K + i0 + (size_t)(j0 + 16 * cb) * ldk);
+                char *mbase = reinterpret_cast<char *>(K + (j0 + 16 * cb) + (size_t)i0 * ldk);
+                if (plain) {
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        gram_d4 v;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = exp_bounded(min_raw(acc[it][r], lnsf2));
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            *reinterpret_cast<double *>(cbase + ((size_t)(16 * it) + (size_t)(JS * r) * ldk) * 8 + voff) = v[r];
+                        if (MODE == 2) *reinterpret_cast<gram_d4 *>(mbase + (size_t)(16 * it) * ldk * 8 + moff) = v;
+                    }
+                } else {
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        if (MODE == 1 && diag && it < cb) continue;     // block above the diagonal
+                        const int gi = i0 + 16 * it + fr;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int gj = j0 + 16 * cb + ((MODE == 2) ? 4 * fk : fk) + JS * r;
+                            double v = exp(fmin(acc[it][r], lnsf2));
+                            if (MODE && gi == gj) v = dval;       // exp(-0) == 1: sf*sf*1 + sn*sn (+ sigmaNoise), exact
+                            if (gi < nr && gj < nc && !(diag && gi < gj)) K[gi + (size_t)gj * ldk] = v;
+                            if (MODE == 2 && gi < nr && gj < nc && (!diag || gi > gj)) K[gj + (size_t)gi * ldk] = v;
+                        }
+                    }
+                }
+            }
+        }
+        u0 = ub + q1;
+    }
+}
+
 __global__ void pad_identity_kernel(double *A, int n, int np, int lda) {
     // zero rows [n,np) x cols [0,np) and rows [0,n) x cols [n,np); ones on the pad diagonal
     const int pad = np - n;
@@ -247,6 +465,7 @@ GramParams make_params(const double *theta, int d, double extra) {
     p.sn2 = theta[d + 1] * theta[d + 1];
     p.extra = extra;
     p.dmode = 0, p.dk = 0, p.dcoef = 0.0;
+    p.lnsf2 = std::log(p.sf2);
     for (int k = 0; k < GP_DMAX; ++k) p.inv_ls2[k] = p.inv_ls[k] = 0.0;
     for (int k = 0; k < d; ++k) {
         p.inv_ls2[k] = 1.0 / (theta[1 + k] * theta[1 + k]);
@@ -257,20 +476,54 @@ GramParams make_params(const double *theta, int d, double extra) {
 
 }  // namespace
 
-// Which form builds the Gram matrices.  Measured on MI355X (tools/gram_perf.py, n = 8192, m = 65536): at d = 8 the per-pair form
-// wins (cross-Gram 1.21 vs 1.24 ms, lower Gram 84 vs 104 us: both are bound by VALU issue and by the load -> barrier -> store
-// life cycle of a tile, not by the store stream -- a store-only kernel with the same tile pattern reaches 5.4 TB/s, memset
-// 6.4 TB/s), at d = 32 the matrix-core form wins (1.95 vs 2.68 ms), so the default switches at d >= 16.
-// GPCORE_GRAM_MFMA=1 / 0 forces one form (read per call: the tests run both in one process).
-static bool gram_mfma(int d) {
+// Which form builds the Gram matrices: 2 = the unit kernel (whole exponent on the matrix cores, d <= 14: every BASELINE configuration),
+// 1 = the LDS-staged matrix-core form (any d; the default from d = 16, where it beats the per-pair form 1.95 vs 2.68 ms at d = 32),
+// 0 = the per-pair form in the reference's own operation order.  GPCORE_GRAM_MFMA=0 forces the per-pair form, =1 a matrix-core form
+// at every d, =2 the LDS-staged one (read per call: the tests run all of them in one process).
+static int gram_form(int d, const GramParams &p, int ldk) {
+    // the unit kernel wants a finite ln sf^2 (sf = 0, inf, NaN: per-pair form, which multiplies by sf^2) and 32-bit store offsets
+    const bool unit_ok = d <= GU_DMAX && std::isfinite(p.lnsf2) && ldk < (1 << 25);
     const char *e = getenv("GPCORE_GRAM_MFMA");
-    return e ? atoi(e) != 0 : d >= 16;
+    if (e) {
+        const int v = atoi(e);
+        if (v == 0) return 0;
+        return (v == 1 && d <= GU_DMAX) ? (unit_ok ? 2 : 0) : 1;
+    }
+    return d <= GU_DMAX ? (unit_ok ? 2 : 0) : (d >= 16 ? 1 : 0);
+}
+
+// `upw` units per wave: about 1.5 waves per resident slot (2 waves per SIMD at this register count), at most 32 -- wave counts that
+// are a multiple of the 2048 slots run in lock step (all load, then all store) and measure up to 25 % slower
+template <int MODE>
+static void launch_unit(hipStream_t s, const double *Xr, int nr, int ldxr, const double *Xc, int nc, int ldxc, int d, const GramParams &p,
+                        const double *cen, int ldcen, double *K, int ldk) {
+    const int nbr = (nr + 63) / 64, nbc = (nc + 63) / 64;
+    const long total = MODE ? 2L * nbr * (nbr + 1) : 4L * nbr * nbc;
+    long upw = (total + 3071) / 3072;
+    if (upw > 32) upw = 32;
+    if (const char *e = getenv("GPCORE_GRAM_UPW")) upw = atoi(e) > 0 ? atoi(e) : upw;
+    const unsigned grid = (unsigned)((total + upw - 1) / upw);
+#define GU_LAUNCH(KS, KR) hipLaunchKernelGGL((gram_unit_kernel<KS, KR, MODE>), dim3(grid), dim3(64), 0, s, Xr, nr, ldxr, Xc, nc, ldxc, d, p, cen, ldcen, K, ldk, nbc, (int)upw, total)
+    if (d <= 2) GU_LAUNCH(1, 1);
+    else if (d <= 4) GU_LAUNCH(2, 1);
+    else if (d <= 6) GU_LAUNCH(2, 2);
+    else if (d <= 8) GU_LAUNCH(3, 2);
+    else if (d <= 10) GU_LAUNCH(3, 3);
+    else if (d <= 12) GU_LAUNCH(4, 3);
+    else GU_LAUNCH(4, 4);
+#undef GU_LAUNCH
 }
 
 void gpk_gram_sym(hipStream_t s, const double *X, int n, int d, int ldx, const double *theta, double *K, int ldk, int full, double extra_diag) {
     GramParams p = make_params(theta, d, extra_diag);
     int nb = (n + GT - 1) / GT;
-    if (gram_mfma(d)) {
+    const int form = gram_form(d, p, ldk);
+    if (form == 2) {
+        if (full) launch_unit<2>(s, X, n, ldx, X, n, ldx, d, p, X, ldx, K, ldk);
+        else launch_unit<1>(s, X, n, ldx, X, n, ldx, d, p, X, ldx, K, ldk);
+        return;
+    }
+    if (form == 1) {
         hipLaunchKernelGGL(gram_mfma_kernel<true>, dim3(nb * (nb + 1) / 2), dim3(256), 0, s, X, n, ldx, X, n, ldx, d, p, X, ldx, K, ldk, full, nb);
         return;
     }
@@ -290,7 +543,12 @@ void gpk_dgram_sym(hipStream_t s, const double *X, int n, int d, int ldx, const 
 void gpk_gram_cross(hipStream_t s, const double *Xs, int m, int ldxs, const double *X, int n, int ldx, int d, const double *theta, double *Ks, int ldks) {
     GramParams p = make_params(theta, d, 0.0);
     int nbr = (m + GT - 1) / GT, nbc = (n + GT - 1) / GT;
-    if (gram_mfma(d)) {   // centre = first TRAINING point for both operands
+    const int form = gram_form(d, p, ldks);
+    if (form == 2) {          // centre = first TRAINING point for both operands
+        launch_unit<0>(s, Xs, m, ldxs, X, n, ldx, d, p, X, ldx, Ks, ldks);
+        return;
+    }
+    if (form == 1) {
         hipLaunchKernelGGL(gram_mfma_kernel<false>, dim3(nbr * nbc), dim3(256), 0, s, Xs, m, ldxs, X, n, ldx, d, p, X, ldx, Ks, ldks, 1, nbr);
         return;
     }
