@@ -64,6 +64,32 @@ def test_c2_fit_round_trips(c2):
     assert np.all(np.triu(L[:256, :256], 1) == 0.0) and L[0, n - 1] == 0.0
 
 
+def test_c2_gram_matrices_rows_against_the_oracle(c2):
+    """The Gram matrices at the BASELINE size (n = 8192, d = 8: 8256 tiles / 33 024 units of the unit kernel, jobs that cross strip
+    boundaries): 96 rows spread over the matrix against the oracle's rows, elementwise 1e-13; exact diagonal; exact symmetry;
+    the lower-only form writes nothing above the diagonal; a 16 384 x 8192 cross-Gram the same way."""
+    ctx, mdl, p = c2
+    n = 8192
+    rows = np.unique(np.concatenate(([0, 1, 63, 64, 65, 4095, 4096, 8190, 8191], np.random.default_rng(3).integers(0, n, 87))))
+    Ko = orc.gram_cross(np.asfortranarray(p["X"][rows]), p["X"], np.concatenate((p["theta"][:-1], [0.0])))
+    diag = p["theta"][0] * p["theta"][0] + p["theta"][-1] * p["theta"][-1]
+    K = ctx.gram_rbf(p["X"], p["theta"])
+    assert np.all(np.diag(K) == diag) and np.array_equal(K, K.T)
+    got = K[rows].copy()
+    got[np.arange(rows.size), rows] = Ko[np.arange(rows.size), rows]       # the oracle's cross form carries no noise term
+    assert np.max(np.abs(got - Ko) / Ko) <= 1e-13
+    out = np.full((n, n), -7.0, order="F")
+    Kl = ctx.gram_rbf(p["X"], p["theta"], full=False, out=out)
+    assert np.array_equal(np.tril(Kl), np.tril(K))
+    assert np.all(Kl[0, 1:] == -7.0) and np.all(Kl[4095, 4096:] == -7.0) and np.all(Kl[np.triu_indices(n, 1)][::4099] == -7.0)
+    del K, Kl, out
+    Xs = synth.config_c2(8192, 8, 16384)["Xs"]
+    Ks = ctx.cross_gram_rbf(Xs, p["X"], p["theta"])
+    rs = np.unique(np.concatenate(([0, 63, 64, 16383], np.random.default_rng(4).integers(0, 16384, 60))))
+    Kso = orc.gram_cross(np.asfortranarray(Xs[rs]), p["X"], p["theta"])
+    assert np.max(np.abs(Ks[rs] - Kso) / Kso) <= 1e-13
+
+
 def test_c2_posterior_identities_and_spot_check(c2):
     ctx, mdl, p = c2
     sf2, sn2 = p["theta"][0] ** 2, p["theta"][-1] ** 2
