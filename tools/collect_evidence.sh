@@ -1,11 +1,12 @@
 #!/bin/bash
 # Round evidence on the GPU box: bench lines of every workload, rocprofv3 kernel stats of the headline command, PMC passes per workload
 # (one counter set per run, kernel-trace only; the program goes directly after `--`), EP sweep timeline, chain-kernel stamps, mesh
-# throughput.  usage (from the repo root on the box): bash tools/collect_evidence.sh <tag> [quick]
+# throughput.  usage (from the repo root on the box): bash tools/collect_evidence.sh <tag> [quick|full] [first stage: 0 bench lines, 1 pmc c2/c3, 2 pmc c4/c5, 3 the rest]
 # Every step appends to $O/progress.log so that a long collection never looks hung.
 set -o pipefail
 TAG=${1:-r03_z}
 QUICK=${2:-}
+FROM=${3:-0}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
@@ -15,24 +16,31 @@ pmc() {   # pmc <name> <bench args...>: FETCH / WRITE / MFMA-busy passes of one 
     local name=$1; shift
     for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
         local tagset=$(echo $set | cut -d' ' -f1)
-        rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/pmc_${name}_$tagset -o p -- python3 $R/bench.py "$@" > $O/pmc_${name}_$tagset.log 2>&1 && say "pmc $name $tagset ok"
+        timeout -k 10 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/pmc_${name}_$tagset -o p -- python3 $R/bench.py "$@" > $O/pmc_${name}_$tagset.log 2>&1 && say "pmc $name $tagset ok"
     done
     python3 $R/tools/pmc_summary.py $O/pmc_${name}_summary.json "rocprofv3 --kernel-trace --pmc <set> --output-format csv -- python3 bench.py $*; one counter set per run (FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE)" $(find $O/pmc_${name}_* -name "*counter_collection.csv") > $O/pmc_${name}_summary.txt 2>&1 && say "pmc $name summary ok"
     rm -rf $O/pmc_${name}_FETCH_SIZE $O/pmc_${name}_WRITE_SIZE $O/pmc_${name}_SQ_VALU_MFMA_BUSY_CYCLES
 }
+if [ $FROM -le 0 ]; then
 python3 $R/bench.py > $O/bench_c2.json 2> $O/bench_c2.err && say "c2 ok"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o c2 -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-c3 > $O/stats.log 2>&1 && say "stats ok"
 cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/bench_c2_kernel_stats.csv 2>/dev/null; rm -rf $O/stats
 python3 $R/bench.py --workload c3 --steps 3 --warmup 1 > $O/bench_c3.json 2> $O/bench_c3.err && say "c3 ok"
 python3 $R/bench.py --workload c4 --steps 2 > $O/bench_c4.json 2> $O/bench_c4.err && say "c4 ok"
 python3 $R/bench.py --workload c5 --steps 1 --warmup 1 > $O/bench_c5.json 2> $O/bench_c5.err && say "c5 ok"
+fi
+if [ $FROM -le 1 ]; then
 pmc c2 --steps 1 --warmup 1 --no-cpu-baseline --no-c3
 pmc c3 --workload c3 --steps 1 --warmup 1
+fi
+if [ $FROM -le 2 ]; then
 # (c4: the fused chain kernel announces its solved rows to a kernel that waits on the side stream; under --pmc the profiler runs one
-#  kernel at a time, so the waiter would only ever time out -- the counters are taken on the two-launch form, same GEMM kernels)
-GPCORE_EP_FUSED=0 pmc c4 --workload c4 --steps 1
+#  kernel at a time, so the waiter would only ever time out -- the counters are taken on the two-launch form, same GEMM kernels, and
+#  without the ep_grid block, whose lockstep batch always runs the fused kernel)
+GPCORE_EP_FUSED=0 pmc c4 --workload c4 --steps 1 --no-c3
 pmc c5 --workload c5 --steps 1 --warmup 1 --test-points 262144
-[ -n "$QUICK" ] && exit 0
+fi
+[ "$QUICK" = "quick" ] && exit 0
 rocprofv3 --kernel-trace -d $O/trace_c4 -o c4 -- python3 $R/tools/ep_sweeps.py 4096 30 > $O/trace_c4.log 2>&1 && say "c4 trace ok"
 python3 $R/tools/trace_breakdown.py $(find $O/trace_c4 -name "*.db" | head -1) 15 > $O/c4_kernel_breakdown.txt 2>&1
 python3 $R/tools/sweep_summary.py $(find $O/trace_c4 -name "*.db" | head -1) > $O/c4_sweep_summary.txt 2>&1
