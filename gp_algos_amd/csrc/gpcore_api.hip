@@ -30,7 +30,8 @@ void gp_prof_end(gp_ctx *ctx, int cls, double work, hipStream_t s) {
 
 namespace {
 
-struct ws_slot { void *p = nullptr; size_t bytes = 0; };
+// tag: what a caller that wants to find its own invariants again next time wrote there (0 = nothing promised; ws_get resets it)
+struct ws_slot { void *p = nullptr; size_t bytes = 0; unsigned long long tag = 0; };
 
 struct ctx_ext { ws_slot ws[WS_COUNT]; std::vector<gp_ctx *> children; };
 
@@ -45,6 +46,7 @@ ctx_ext *ext_of(gp_ctx *ctx) { return &static_cast<gp_ctx_full *>(ctx)->ext; }
 
 gp_status ws_get(gp_ctx *ctx, int slot, size_t bytes, double **out) {
     ws_slot &w = ext_of(ctx)->ws[slot];
+    w.tag = 0;
     if (w.bytes < bytes) {
         if (w.p) { GP_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(w.p); w.p = nullptr; w.bytes = 0; }
         size_t want = bytes + bytes / 8;
@@ -56,6 +58,19 @@ gp_status ws_get(gp_ctx *ctx, int slot, size_t bytes, double **out) {
     *out = static_cast<double *>(w.p);
     return GP_OK;
 }
+
+// ws_get for a caller whose buffer keeps an invariant between calls (zeros that no kernel of its path ever overwrites): *kept says
+// whether the slot still carries `tag` from the same caller -- nobody else has asked for the slot since and it was not reallocated.
+gp_status ws_get_keep(gp_ctx *ctx, int slot, size_t bytes, double **out, unsigned long long tag, bool *kept) {
+    ws_slot &w = ext_of(ctx)->ws[slot];
+    const unsigned long long before = w.tag;
+    const void *pb = w.p;
+    GP_TRY(ws_get(ctx, slot, bytes, out));
+    *kept = tag != 0 && before == tag && pb == w.p;
+    w.tag = tag;
+    return GP_OK;
+}
+void ws_forget(gp_ctx *ctx, int slot) { ext_of(ctx)->ws[slot].tag = 0; }
 
 gp_status upload_2d(gp_ctx *ctx, double *dst, int ldd, const double *src, int lds, int rows, int cols) {
     if (rows <= 0 || cols <= 0) return GP_OK;
@@ -413,8 +428,10 @@ void solve_rows_lower(gp_ctx *ctx, double *Vt, int mp, const double *L, int np, 
 // right of it per outer block) measured 2-4 % slower at n = 4096 (the long-K GEMM multiplies the zero lower part of the
 // outer block and the K = 128 updates lose their width); with a lockstep batch the launches are wide enough either way and
 // the K = 128 form is bound by re-reading and re-writing the later columns of T, so batches use the two-level form.
+// lower_is_zero: the caller guarantees zeros below T's diagonal blocks (they are never written here), so only the blocks on and above
+// the diagonal are reset
 void inverse_transpose_lower(gp_ctx *ctx, double *T, const double *L, int np, int ldl, const double *dinv, int count = 1, size_t strideT = 0,
-                             size_t strideL = 0, size_t strideDinv = 0) {
+                             size_t strideL = 0, size_t strideDinv = 0, bool lower_is_zero = false) {
     hipStream_t s = ctx->stream;
     gp_batch btrsm, bgemm;
     btrsm.count = bgemm.count = count;
@@ -424,7 +441,10 @@ void inverse_transpose_lower(gp_ctx *ctx, double *T, const double *L, int np, in
     // to the right of it is updated once per outer block with K = OB.  OB = 128 is the plain right-looking form.
     const int ob_env = gp_env_blocks("GPCORE_TINV_OUTER");
     const int OB = ob_env ? ob_env : (count >= 4 ? GP_OUTER : GP_NB);
-    for (int g = 0; g < count; ++g) gpk_set_identity(s, T + g * strideT, np, np);
+    for (int g = 0; g < count; ++g) {
+        if (lower_is_zero) gpk_set_identity_upper(s, T + g * strideT, np, np);
+        else gpk_set_identity(s, T + g * strideT, np, np);
+    }
     for (int c0 = 0; c0 < np; c0 += OB) {
         const int c1 = std::min(np, c0 + OB);
         for (int k0 = c0; k0 < c1; k0 += GP_NB) {
@@ -1479,13 +1499,18 @@ gp_status lml_worker_setup(lml_worker &w, const double *X, int n, int d, int ldx
     w.sPart = (size_t)gpk_lml_grad_partials_size(n, d);
     GP_TRY(ws_get(ctx, WS_A, sizeof(double) * ((size_t)n * d + np), &w.dX));
     w.dy = w.dX + (size_t)n * d;
-    GP_TRY(ws_get(ctx, WS_B, sizeof(double) * w.sL * G, &w.L));
+    // L and T keep zeros that nothing in this path overwrites (the factors' upper triangles and the 127 rows under y^T; the blocks
+    // below T's diagonal): a call that finds its own tag on the slot does not clear 4 GB per worker again
+    const unsigned long long tag = 0x4c4d4c0000000000ull | ((unsigned long long)np << 16) | (unsigned long long)G;
+    bool keptL = false, keptT = false;
+    GP_TRY(ws_get_keep(ctx, WS_B, sizeof(double) * w.sL * G, &w.L, tag, &keptL));
     GP_TRY(ws_get(ctx, WS_C, sizeof(double) * w.sSmall * G, &w.small));
     double *ip = nullptr;
     GP_TRY(ws_get(ctx, WS_SUMSQ, sizeof(double) * (size_t)(G + 2), &ip));
     w.info = reinterpret_cast<int *>(ip);
     if (nparams > 0) {
-        GP_TRY(ws_get(ctx, WS_VT, sizeof(double) * w.sT * G, &w.T));
+        GP_TRY(ws_get_keep(ctx, WS_VT, sizeof(double) * w.sT * G, &w.T, tag, &keptT));
+        if (!keptT) GP_HIP(ctx, hipMemsetAsync(w.T, 0, sizeof(double) * w.sT * G, ctx->stream));
         GP_TRY(ws_get(ctx, WS_D, sizeof(double) * w.sT * G, &w.Kinv));
         GP_TRY(ws_get(ctx, WS_PARTIAL, sizeof(double) * w.sPart * G, &w.partials));
         GP_TRY(ws_get(ctx, WS_E, sizeof(double) * (size_t)LML_GEMV_CHUNKS * np * G, &w.gemv_part));
@@ -1493,7 +1518,7 @@ gp_status lml_worker_setup(lml_worker &w, const double *X, int n, int d, int ldx
     GP_TRY(upload_2d(ctx, w.dX, n, X, ldx, n, d));
     GP_HIP(ctx, hipMemsetAsync(w.dy, 0, sizeof(double) * np, ctx->stream));
     GP_TRY(upload_2d(ctx, w.dy, n, y, n, n, 1));
-    GP_HIP(ctx, hipMemsetAsync(w.L, 0, sizeof(double) * w.sL * G, ctx->stream));   // upper triangles and the 127 spare rows under y^T
+    if (!keptL) GP_HIP(ctx, hipMemsetAsync(w.L, 0, sizeof(double) * w.sL * G, ctx->stream));   // upper triangles and the 127 spare rows under y^T
     w.hres.assign((size_t)72 * G, 0.0);
     w.hinfo.assign(G, 0);
     return GP_OK;
@@ -1521,7 +1546,7 @@ gp_status lml_worker_eval(lml_worker &w, const double *thetas, int g, int nparam
         gpk_lml(s, Lj, n, ldl, w.tvec(j), w.res(j));
     }
     if (nparams > 0) {
-        inverse_transpose_lower(ctx, w.T, w.L, np, ldl, w.small, g, w.sT, w.sL, w.sSmall);     // T = L^-T (upper triangular)
+        inverse_transpose_lower(ctx, w.T, w.L, np, ldl, w.small, g, w.sT, w.sL, w.sSmall, true);     // T = L^-T (upper triangular)
         gp_batch bk;
         bk.count = g, bk.s0 = bk.s1 = bk.s2 = w.sT;
         gp_prof_begin(ctx, GP_PROF_SYRK);
@@ -1529,7 +1554,7 @@ gp_status lml_worker_eval(lml_worker &w, const double *thetas, int g, int nparam
         gp_prof_end(ctx, GP_PROF_SYRK, (double)g * np * np * np / 3.0);
         for (int j = 0; j < g; ++j) {
             // alpha = L^-T t = T t: one matrix-vector pass over the T already here, not np/128 substitution steps
-            gpk_gemv_rows(s, w.T + j * w.sT, np, np, np, w.tvec(j), w.alpha(j), w.gemv_part + (size_t)j * LML_GEMV_CHUNKS * np, LML_GEMV_CHUNKS);
+            gpk_gemv_rows(s, w.T + j * w.sT, np, np, np, w.tvec(j), w.alpha(j), w.gemv_part + (size_t)j * LML_GEMV_CHUNKS * np, LML_GEMV_CHUNKS, 1);
             gpk_lml_grad_traces(s, w.dX, n, d, n, thetas + (size_t)j * P, w.alpha(j), w.Kinv + j * w.sT, np, w.partials + j * w.sPart, w.res(j) + 1);
         }
     }
@@ -1540,6 +1565,7 @@ gp_status lml_worker_eval(lml_worker &w, const double *thetas, int g, int nparam
     GP_HIP(ctx, hipStreamSynchronize(s));
     for (int j = 0; j < g; ++j) {
         const int h = w.hinfo[j];
+        if (h) { ws_forget(ctx, WS_B); ws_forget(ctx, WS_VT); }    // a failed factorisation may have left NaN in the rows that ride along
         if (info) info[j] = h;
         lml[j] = h ? NAN : w.hres[(size_t)72 * j];
         for (int p = 0; p < nparams; ++p) grad[(size_t)j * nparams + p] = h ? NAN : w.hres[(size_t)72 * j + 1 + p];

@@ -135,6 +135,7 @@ void gpk_transpose(hipStream_t s, double *dst, int ldd, const double *src, int l
 // stage = 0: dst (lower form) <- (upper form src)^T, block-lower part and diagonal blocks only.
 void gpk_lw_transpose(hipStream_t s, double *dst, int ldd, const double *src, int lds, int np, int stage);
 void gpk_set_identity(hipStream_t s, double *A, int n, int lda);
+void gpk_set_identity_upper(hipStream_t s, double *A, int n, int lda);   // the 128-blocks on and above the diagonal only (n a multiple of 128)
 void gpk_add_diag(hipStream_t s, double *A, int n, int lda, double v);   // A(i,i) += v, i < n
 // LML-gradient traces (GpPredictor.scala:70-78 fused): out[0..d+1] = g_p for W = alpha alpha^T - Kinv (lower triangle of Kinv read)
 void gpk_lml_grad_traces(hipStream_t s, const double *X, int n, int d, int ldx, const double *theta, const double *alpha,
@@ -143,7 +144,7 @@ int gpk_lml_grad_partials_size(int n, int d);
 // y (len M) -= A (M x 128, lda) * x (128)
 void gpk_gemv_panel_sub(hipStream_t s, const double *A, int M, int lda, const double *x, double *y);
 // out[i] = sum_j Ks(i,j) * alpha[j], deterministic, j ascending per row chunk
-void gpk_gemv_rows(hipStream_t s, const double *Ks, int m, int n, int ldks, const double *alpha, double *out, double *partial, int nchunk);
+void gpk_gemv_rows(hipStream_t s, const double *Ks, int m, int n, int ldks, const double *alpha, double *out, double *partial, int nchunk, int upper_blocks = 0);
 // lml = -0.5 t.t - sum log L_ii - n/2 log 2pi with t = L^-1 y  (y.alpha = |L^-1 y|^2; n real rows)
 void gpk_lml(hipStream_t s, const double *L, int n, int ldl, const double *t, double *out);
 // var[i] = kss - sumsq[i]

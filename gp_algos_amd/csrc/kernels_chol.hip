@@ -26,13 +26,15 @@ __global__ __launch_bounds__(256) void gemv_panel_sub_kernel(const double *__res
 }
 
 // partial[chunk][i] = sum_{j in chunk} Ks(i,j) alpha[j]  (j ascending); then out[i] = sum_chunk partial (ascending)
+// upper_blocks: Ks is block upper triangular (128-blocks) -- row i starts at the first column of its diagonal block (uniform per wave)
 __global__ __launch_bounds__(256) void gemv_rows_kernel(const double *__restrict__ Ks, int m, int n, int ldks,
                                                         const double *__restrict__ alpha, double *__restrict__ partial,
-                                                        int nchunk) {
+                                                        int nchunk, int upper_blocks) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int ch = blockIdx.y;
     const int per = (n + nchunk - 1) / nchunk;
-    const int j0 = ch * per, j1 = min(n, j0 + per);
+    const int j1 = min(n, ch * per + per);
+    const int j0 = upper_blocks ? max(ch * per, i & ~127) : ch * per;
     if (i >= m) return;
     double acc = 0.0;
 #pragma unroll 8
@@ -157,6 +159,14 @@ __global__ void set_identity_kernel(double *A, int n, int lda) {
     for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
         int i = (int)(e % n), j = (int)(e / n);
         A[i + (size_t)j * lda] = (i == j) ? 1.0 : 0.0;
+    }
+}
+
+// column j (blockIdx.y, strided): rows 0 .. end of j's diagonal block
+__global__ void set_identity_upper_kernel(double *A, int n, int lda) {
+    for (int j = blockIdx.y; j < n; j += gridDim.y) {
+        const int rows = (j & ~127) + 128;
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += gridDim.x * blockDim.x) A[i + (size_t)j * lda] = (i == j) ? 1.0 : 0.0;
     }
 }
 
@@ -321,6 +331,9 @@ void gpk_add_diag(hipStream_t s, double *A, int n, int lda, double v) {
 void gpk_set_identity(hipStream_t s, double *A, int n, int lda) {
     hipLaunchKernelGGL(set_identity_kernel, dim3(1024), dim3(256), 0, s, A, n, lda);
 }
+void gpk_set_identity_upper(hipStream_t s, double *A, int n, int lda) {
+    hipLaunchKernelGGL(set_identity_upper_kernel, dim3(4, n < 65535 ? n : 65535), dim3(256), 0, s, A, n, lda);
+}
 constexpr int TR_MAX_WG = 1024;   // 4 per CU: enough to hide the Kinv stream, few enough that the fixed-order reduce stays short
 int gpk_lml_grad_partials_size(int n, int d) {
     (void)n;
@@ -349,8 +362,8 @@ void gpk_gemv_panel_sub(hipStream_t s, const double *A, int M, int lda, const do
     if (M <= 0) return;
     hipLaunchKernelGGL(gemv_panel_sub_kernel, dim3((M + 255) / 256), dim3(256), 0, s, A, M, lda, x, y);
 }
-void gpk_gemv_rows(hipStream_t s, const double *Ks, int m, int n, int ldks, const double *alpha, double *out, double *partial, int nchunk) {
-    hipLaunchKernelGGL(gemv_rows_kernel, dim3((m + 255) / 256, nchunk), dim3(256), 0, s, Ks, m, n, ldks, alpha, partial, nchunk);
+void gpk_gemv_rows(hipStream_t s, const double *Ks, int m, int n, int ldks, const double *alpha, double *out, double *partial, int nchunk, int upper_blocks) {
+    hipLaunchKernelGGL(gemv_rows_kernel, dim3((m + 255) / 256, nchunk), dim3(256), 0, s, Ks, m, n, ldks, alpha, partial, nchunk, upper_blocks);
     hipLaunchKernelGGL(reduce_chunks_kernel, dim3((m + 255) / 256), dim3(256), 0, s, partial, m, nchunk, out);
 }
 void gpk_lml(hipStream_t s, const double *L, int n, int ldl, const double *t, double *out) {

@@ -75,6 +75,18 @@ def test_lockstep_batch_with_a_non_pd_member_past_one_outer_panel(ctx, monkeypat
         ol, og = orc.lml_grad(X, y, thetas[b])
         assert info[b] == 0 and abs(lml[b] - ol) <= TOL_LML * abs(ol)
         assert np.max(np.abs(grad[b] - og)) <= TOL_GRAD * np.max(np.abs(og))
+    # the workers keep the zeros of their factor and inverse buffers from call to call (no 4 GB clear per call); a failed member
+    # makes them clear again, and the calls after it -- same shape, then another shape, then the first again -- give the same bits
+    good = thetas[[0, 1, 3, 4, 0]]
+    l1, g1, i1 = ctx.lml_grad_batched(X, y, good)
+    l2, g2, i2 = ctx.lml_grad_batched(X, y, good)
+    assert np.all(i1 == 0) and np.array_equal(l1, l2) and np.array_equal(g1, g2)
+    assert np.array_equal(l1[:4], lml[[0, 1, 3, 4]]) and np.array_equal(g1[:4], grad[[0, 1, 3, 4]]) and l1[4] == l1[0]
+    ctx.lml_grad_batched(X[:300].copy(order="F"), y[:300], good[:2])
+    K = ctx.gram_rbf(X, good[0])          # another user of the same workspace slot in between
+    assert K.shape == (670, 670)
+    l3, g3, _ = ctx.lml_grad_batched(X, y, good)
+    assert np.array_equal(l1, l3) and np.array_equal(g1, g3)
 
 
 # ---- C3 at full size -------------------------------------------------------------------------------------------------------
