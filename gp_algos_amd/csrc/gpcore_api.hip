@@ -728,8 +728,8 @@ gp_status gp_ctx_create(int device, void *stream, gp_ctx **out) {
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_b, hipEventDisableTiming);
     if (const char *la = getenv("GPCORE_LOOKAHEAD")) ctx->lookahead = atoi(la) != 0 ? 1 : 0;
     if (e == hipSuccess) e = hipMalloc(&ctx->d_scalars, sizeof(double) * 256);
-    if (e == hipSuccess) e = hipMalloc(&ctx->d_info, sizeof(int) * 4);
-    if (e == hipSuccess) e = hipMemset(ctx->d_info, 0, sizeof(int) * 4);
+    if (e == hipSuccess) e = hipMalloc(&ctx->d_info, sizeof(int) * 8);
+    if (e == hipSuccess) e = hipMemset(ctx->d_info, 0, sizeof(int) * 8);
     if (e == hipSuccess && (gpk_init_diag_kernels() != 0 || gpk_init_gemm_kernels() != 0)) e = hipErrorInvalidValue;
     if (e != hipSuccess) { delete ctx; return GP_EHIP; }
     *out = ctx;
@@ -869,7 +869,7 @@ gp_status gp_gram_rbf_dev(gp_ctx *ctx, const double *dX, int n, int d, int ldx, 
     GP_REQUIRE(ctx, n >= 0 && d >= 1 && d <= 64 && ldx >= n && ldk >= n, "bad dimensions (1 <= d <= 64)");
     if (n == 0) return GP_OK;
     gp_prof_begin(ctx, GP_PROF_GRAM);
-    gpk_gram_sym(ctx->stream, dX, n, d, ldx, theta, dK, ldk, uplo == GP_FULL, 0.0);
+    gpk_gram_sym(ctx->stream, dX, n, d, ldx, theta, dK, ldk, uplo == GP_FULL, 0.0, gp_gram_flag(ctx));
     gp_prof_end(ctx, GP_PROF_GRAM, uplo == GP_FULL ? 8.0 * n * (double)n + 8.0 * n * d : 8.0 * n * (n + 1.0) / 2.0 + 8.0 * n * d);
     return GP_OK;
 }
@@ -918,7 +918,7 @@ gp_status gp_cross_gram_rbf(gp_ctx *ctx, const double *Xs, int m, int ldxs, cons
     GP_TRY(ws_get(ctx, WS_B, sizeof(double) * (size_t)m * n, &dK));
     GP_TRY(upload_2d(ctx, dXs, m, Xs, ldxs, m, d));
     GP_TRY(upload_2d(ctx, dX, n, X, ldx, n, d));
-    gpk_gram_cross(ctx->stream, dXs, m, m, dX, n, n, d, theta, dK, m);
+    gpk_gram_cross(ctx->stream, dXs, m, m, dX, n, n, d, theta, dK, m, gp_gram_flag(ctx));
     return download_2d(ctx, Ks, ldks, dK, m, m, n);
 }
 
@@ -973,7 +973,7 @@ gp_status gp_model_refit_dev(gp_model *m, const double *theta, double sigma_nois
     m->sigma_noise = sigma_noise;
     gp_prof_begin(ctx, GP_PROF_GRAM);
     if (m->kind == 1) gpk_co2_gram(ctx->stream, m->dX, m->n, m->dX, m->n, theta, 0, m->dL, m->ldl, 1, 0, std::isnan(sigma_noise) ? 0.0 : sigma_noise);
-    else gpk_gram_sym(ctx->stream, m->dX, m->n, m->d, m->n, theta, m->dL, m->ldl, 0, std::isnan(sigma_noise) ? 0.0 : sigma_noise);
+    else gpk_gram_sym(ctx->stream, m->dX, m->n, m->d, m->n, theta, m->dL, m->ldl, 0, std::isnan(sigma_noise) ? 0.0 : sigma_noise, gp_gram_flag(ctx));
     gp_prof_end(ctx, GP_PROF_GRAM, 8.0 * m->n * (m->n + 1.0) / 2.0 + 8.0 * m->n * m->d);
     model_factor(m);
     GP_LAUNCH_CHECK(ctx);
@@ -1144,7 +1144,7 @@ static gp_status predict_core(gp_model *mdl, const double *dXs, int m, int ldxs,
     }
     gp_prof_begin(ctx, GP_PROF_GRAM);
     if (mdl->kind == 1) gpk_co2_gram(s, dXs, m, mdl->dX, n, mdl->theta.data(), 0, Vt, mp, 0, 1, 0.0);
-    else gpk_gram_cross(s, dXs, m, ldxs, mdl->dX, n, n, mdl->d, mdl->theta.data(), Vt, mp);
+    else gpk_gram_cross(s, dXs, m, ldxs, mdl->dX, n, n, mdl->d, mdl->theta.data(), Vt, mp, gp_gram_flag(ctx));
     gp_prof_end(ctx, GP_PROF_GRAM, 8.0 * m * (double)n + 8.0 * (m + n) * mdl->d);
     // sumsq and the mean accumulate inside the row-panel solves: var = kss - |v|^2, mean = v . (L^-1 y)  (= K* alpha)
     double *dots = partial;
@@ -1220,7 +1220,7 @@ gp_status gp_predict(gp_model *mdl, const double *Xs, int m, int ldxs, double *m
         double *dC;
         GP_TRY(ws_get(ctx, WS_D, sizeof(double) * (size_t)mp * mp, &dC));
         if (mdl->kind == 1) gpk_co2_gram(ctx->stream, dXs, m, dXs, m, mdl->theta.data(), 0, dC, mp, 1, 1, 0.0);
-        else gpk_gram_sym(ctx->stream, dXs, m, d, m, mdl->theta.data(), dC, mp, 1, 0.0);
+        else gpk_gram_sym(ctx->stream, dXs, m, d, m, mdl->theta.data(), dC, mp, 1, 0.0, gp_gram_flag(ctx));
         gpk_pad_identity(ctx->stream, dC, m, mp, mp);
         gp_prof_begin(ctx, GP_PROF_SYRK);
         gpk_gemm_nt(ctx->stream, mp, mp, mdl->np, -1.0, Vt, mp, Vt, mp, 1.0, dC, mp, 1);
@@ -1320,7 +1320,7 @@ extern "C" gp_status gp_posterior_from_factor(gp_ctx *ctx, const double *X, int 
     GP_TRY(upload_2d(ctx, dX, n, X, ldx, n, d));
     GP_HIP(ctx, hipMemsetAsync(Vt, 0, sizeof(double) * (size_t)mp * np, s));
     gp_prof_begin(ctx, GP_PROF_GRAM);
-    gpk_gram_cross(s, dXs, m, m, dX, n, n, d, theta, Vt, mp);
+    gpk_gram_cross(s, dXs, m, m, dX, n, n, d, theta, Vt, mp, gp_gram_flag(ctx));
     gp_prof_end(ctx, GP_PROF_GRAM, 8.0 * m * (double)n + 8.0 * (m + n) * d);
     GP_TRY(posterior_rows(ctx, Vt, m, mp, f, dout, dout + mp));
     GP_TRY(download_2d(ctx, mean, m, dout, m, m, 1));
@@ -1332,7 +1332,7 @@ extern "C" gp_status gp_posterior_from_factor(gp_ctx *ctx, const double *X, int 
     if (cov) {   // buildKernelMatrix(kernelFunc, testData) - vMatrix.t * vMatrix   (:56)
         double *dC;
         GP_TRY(ws_get(ctx, WS_D, sizeof(double) * (size_t)mp * mp, &dC));
-        gpk_gram_sym(s, dXs, m, d, m, theta, dC, mp, 1, 0.0);
+        gpk_gram_sym(s, dXs, m, d, m, theta, dC, mp, 1, 0.0, gp_gram_flag(ctx));
         gpk_pad_identity(s, dC, m, mp, mp);
         GP_TRY(cov_finish(ctx, dC, m, mp, Vt, np, cov, ldc));
     }
@@ -1534,7 +1534,7 @@ gp_status lml_worker_eval(lml_worker &w, const double *thetas, int g, int nparam
     for (int j = 0; j < g; ++j) {
         double *Lj = w.L + j * w.sL;
         gp_prof_begin(ctx, GP_PROF_GRAM);
-        gpk_gram_sym(s, w.dX, n, d, n, thetas + (size_t)j * P, Lj, ldl, 0, extra);
+        gpk_gram_sym(s, w.dX, n, d, n, thetas + (size_t)j * P, Lj, ldl, 0, extra, gp_gram_flag(ctx));
         gp_prof_end(ctx, GP_PROF_GRAM, 8.0 * n * (n + 1.0) / 2.0 + 8.0 * n * d);
         gpk_pad_identity(s, Lj, n, np, ldl);
         gpk_copy_strided(s, Lj + np, (size_t)ldl, w.dy, 1, np);       // y^T rides through the factorisation in row np

@@ -1909,7 +1909,7 @@ static gp_status ep_eval_lockstep(gp_ctx *ctx, const double *X, int n, int d, in
         if (next >= B) return GP_OK;
         const int b = next++;
         gp_ep *v = sl.ep[g];
-        gpk_gram_sym(ctx->stream, dX, n, d, n, thetas + (size_t)b * P, v->K, np, 1, 0.0);
+        gpk_gram_sym(ctx->stream, dX, n, d, n, thetas + (size_t)b * P, v->K, np, 1, 0.0, gp_gram_flag(ctx));
         GP_TRY(ep_start(v));
         slot_b[g] = b, slot_j[g] = 0;
         std::fill(cur.begin() + (size_t)g * 2 * n, cur.begin() + (size_t)(g + 1) * 2 * n, 0.0);
@@ -2008,7 +2008,7 @@ static gp_status ep_eval_batched(gp_ctx *ctx, const double *X, int n, int d, int
         while (st == GP_OK) {
             const int b = next.fetch_add(1);
             if (b >= B) break;
-            gpk_gram_sym(c->stream, dX, n, d, n, thetas + (size_t)b * P, ep->K, ep->np, 1, 0.0);
+            gpk_gram_sym(c->stream, dX, n, d, n, thetas + (size_t)b * P, ep->K, ep->np, 1, 0.0, gp_gram_flag(c));
             st = ep_start(ep);
             int j = 0, h = 0;
             std::fill(tau.begin(), tau.end(), 0.0);

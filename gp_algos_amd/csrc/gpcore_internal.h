@@ -114,9 +114,12 @@ void gpk_gemm_k128_sub(hipStream_t s, int M, int N, const double *A, int lda, co
 void gpk_gemm_nt_rowred(hipStream_t s, int M, int N, int K, const double *A, int lda, const double *B, int ldb, double *C, int ldc,
                         double *sumsq, const double *tvec, double *dots);
 // ARD-RBF Gram.  theta on host.  symmetric: Xb == Xa, noise on the diagonal, tiles bi >= bj only (mirrored if full).
-void gpk_gram_sym(hipStream_t s, const double *X, int n, int d, int ldx, const double *theta, double *K, int ldk, int full, double extra_diag);
+// far_flag: one int of device memory owned by the caller's context and used in stream order (gp_gram_flag(ctx)); nullptr = the per-pair
+// kernel without the scan
+void gpk_gram_sym(hipStream_t s, const double *X, int n, int d, int ldx, const double *theta, double *K, int ldk, int full, double extra_diag, int *far_flag);
 void gpk_dgram_sym(hipStream_t s, const double *X, int n, int d, int ldx, const double *theta, int pos, double *D, int ldd);
-void gpk_gram_cross(hipStream_t s, const double *Xs, int m, int ldxs, const double *X, int n, int ldx, int d, const double *theta, double *Ks, int ldks);
+void gpk_gram_cross(hipStream_t s, const double *Xs, int m, int ldxs, const double *X, int n, int ldx, int d, const double *theta, double *Ks, int ldks, int *far_flag);
+inline int *gp_gram_flag(gp_ctx *ctx) { return ctx->d_info + 4; }     // d_info holds 8 ints: [0..3] factorisation status, [4] the Gram scan's flag
 // Co2Kernel (gp/regression/Co2Prediction.scala:29-137), 1-D inputs, theta = hp1..hp11 on the host; pos = 0: kernel, 1..11: derivative
 void gpk_co2_gram(hipStream_t s, const double *xr, int nr, const double *xc, int nc, const double *theta, int pos, double *K, int ldk, int sym,
                   int full, double extra);

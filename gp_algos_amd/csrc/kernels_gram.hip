@@ -9,6 +9,7 @@
 // (read as LDS broadcasts).  The symmetric builder evaluates tiles on/below the diagonal only, like
 // the reference's j <= i loop, and mirrors through an LDS transpose so both stores are coalesced.
 #include "gpcore_internal.h"
+#include <atomic>
 
 namespace {
 
@@ -39,7 +40,9 @@ template <bool SYM, bool DER = false>
 __global__ __launch_bounds__(256) void gram_rbf_kernel(const double *__restrict__ Xr, int nr, int ldxr,
                                                        const double *__restrict__ Xc, int nc, int ldxc, int d,
                                                        GramParams prm, double *__restrict__ K, int ldk, int full,
-                                                       int nbr) {
+                                                       int nbr, const int *__restrict__ far_flag = nullptr, int epoch = 0) {
+    // launched behind the unit kernel as its other half: works only when the scan found a point beyond GRAM_NORM_LIMIT (see there)
+    if (far_flag && *far_flag != epoch) return;
     __shared__ double xcs[DC][GT];
     __shared__ double tile[SYM ? GT * (GT + 1) : 1];
     int bi, bj;
@@ -222,10 +225,12 @@ __global__ __launch_bounds__(256) void gram_mfma_kernel(const double *__restrict
 //   * MFMA operand roles put the ROW index on lane & 15: each store instruction writes 4 full 128-byte lines.  When the mirrored
 //     half is wanted the column points are fed in the order 4 (fr & 3) + (fr >> 2), which leaves each lane with 4 CONSECUTIVE
 //     columns -> the mirror is one 32-byte store per lane and block (no transpose through LDS).
-// Rounding: the error of the exponent is a few ulp of |z|^2 (absolute), so a wave whose strip or tile holds a point with
-// |z|^2 > GRAM_NORM_LIMIT takes that tile through the reference's per-pair sum instead (raw features, lane = row, the same bits as
-// gram_rbf_kernel): relative error of K below 5e-14 on the fast path, the reference's own rounding on the other, whatever the
-// spread of the data.
+// Rounding: the error of the exponent is a few ulp of |z|^2 (absolute), i.e. the RELATIVE error of K grows with the spread of the data
+// in length scales.  So every call is three launches: gram_far_kernel scans the points (|z|^2 against GRAM_NORM_LIMIT, 2-3 us), this
+// kernel builds the matrix when none is far (relative error below 5e-14), and gram_rbf_kernel -- the per-pair sum in the reference's
+// own order -- builds it otherwise; the half that is not needed returns at its first instruction.  No host round trip, and wide
+// data costs what it cost in rounds 1-2.  (A per-tile choice inside this kernel was tried first: one wave per 64 x 64 tile on the
+// vector unit runs at a third of gram_rbf_kernel's speed -- profiles/r03_h_gram_scales.log.)
 // Measured at n = 8192, m = 65536, d = 8 (lab): lower 84 -> 59 us (4.6 TB/s), mirrored 121 -> 110 us, cross 1.17 -> 0.86 ms (5.0 TB/s).
 constexpr double GRAM_NORM_LIMIT = 64.0;
 constexpr int GU_DMAX = 14;
@@ -259,8 +264,8 @@ __device__ __forceinline__ double min_raw(double a, double b) {
 }
 
 template <int KS, int KR, bool ROW>
-__device__ __forceinline__ double unit_operand(const double (&raw)[KR], int d, const double (&cen)[KR], const double (&il)[KR], int fk, double lnsf2,
-                                                double (&z)[KS]) {
+__device__ __forceinline__ void unit_operand(const double (&raw)[KR], int d, const double (&cen)[KR], const double (&il)[KR], int fk, double lnsf2,
+                                              double (&z)[KS]) {
     double part = 0.0;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) z[ks] = 0.0;
@@ -279,14 +284,31 @@ __device__ __forceinline__ double unit_operand(const double (&raw)[KR], int d, c
         if (k == d) z[ks] = ROW ? hn : 1.0;
         if (k == d + 1) z[ks] = ROW ? 1.0 : hn;
     }
-    return part;   // |z|^2 of this lane's point
+}
+
+// The scan in front of the unit kernel: one thread per point, |z|^2 = sum_k ((x_k - c_k) / l_k)^2 against GRAM_NORM_LIMIT (NaN counts
+// as far).  A far point writes this call's epoch into the flag; nobody ever has to clear it (epochs are unique per process).
+__global__ __launch_bounds__(256) void gram_far_kernel(const double *__restrict__ Xa, int na, int ldxa, const double *__restrict__ Xb, int nb, int ldxb,
+                                                       int d, GramParams prm, const double *__restrict__ cenp, int ldcen, int *__restrict__ far_flag,
+                                                       int epoch) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= na + nb) return;
+    const double *xp = i < na ? Xa + i : Xb + (i - na);
+    const int ld = i < na ? ldxa : ldxb;
+    double z2 = 0.0;
+    for (int k = 0; k < d; ++k) {
+        const double v = (xp[(size_t)k * ld] - cenp[(size_t)k * ldcen]) * prm.inv_ls[k];
+        z2 = fma(v, v, z2);
+    }
+    if (!(z2 <= GRAM_NORM_LIMIT)) *far_flag = epoch;
 }
 
 // MODE 0: cross-Gram (all tiles); 1: symmetric, lower triangle only; 2: symmetric, mirrored
 template <int KS, int KR, int MODE>
 __global__ __launch_bounds__(64) void gram_unit_kernel(const double *__restrict__ Xr, int nr, int ldxr, const double *__restrict__ Xc, int nc, int ldxc,
                                                        int d, GramParams prm, const double *__restrict__ cenp, int ldcen, double *__restrict__ K,
-                                                       int ldk, int nbc, int upw, long total) {
+                                                       int ldk, int nbc, int upw, long total, const int *__restrict__ far_flag, int epoch) {
+    if (*far_flag == epoch) return;      // a point beyond GRAM_NORM_LIMIT: the per-pair kernel launched behind this one builds the matrix
     const int lane = threadIdx.x, fr = lane & 15, fk = lane >> 4;
     long u0 = (long)blockIdx.x * upw;
     const long u1 = u0 + upw < total ? u0 + upw : total;
@@ -328,10 +350,8 @@ __global__ __launch_bounds__(64) void gram_unit_kernel(const double *__restrict_
 #pragma unroll
             for (int ks = 0; ks < KR; ++ks) raw[b][ks] = xp[(size_t)min(4 * ks + fk, d - 1) * ldxr];
         }
-        double rmax = 0.0;
 #pragma unroll
-        for (int b = 0; b < 4; ++b) rmax = fmax(rmax, unit_operand<KS, KR, true>(raw[b], d, cen, il, fk, 0.0, zr[b]));
-        const bool rowbig = __any(!(rmax <= GRAM_NORM_LIMIT));
+        for (int b = 0; b < 4; ++b) unit_operand<KS, KR, true>(raw[b], d, cen, il, fk, 0.0, zr[b]);
         const int c0 = q0 >> 2, c1 = (q1 + 3) >> 2;
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
@@ -340,9 +360,8 @@ __global__ __launch_bounds__(64) void gram_unit_kernel(const double *__restrict_
             for (int ks = 0; ks < KR; ++ks) raw[b][ks] = xp[(size_t)min(4 * ks + fk, d - 1) * ldxc];
         }
         for (int c = c0; c < c1; ++c) {
-            double cmax = 0.0;
 #pragma unroll
-            for (int b = 0; b < 4; ++b) cmax = fmax(cmax, unit_operand<KS, KR, false>(raw[b], d, cen, il, fk, lnsf2, zc[b]));
+            for (int b = 0; b < 4; ++b) unit_operand<KS, KR, false>(raw[b], d, cen, il, fk, lnsf2, zc[b]);
             if (c + 1 < c1) {
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
@@ -354,30 +373,6 @@ __global__ __launch_bounds__(64) void gram_unit_kernel(const double *__restrict_
             const int j0 = c * 64;
             const bool diag = MODE && bi == c;
             const int cbs = max(q0 - 4 * c, 0), cbe = min(q1 - 4 * c, 4);
-            if (rowbig || __any(!(cmax <= GRAM_NORM_LIMIT))) {
-                // per-pair path: the reference's own sum (x_ik - x_jk) l_k^-2 (x_ik - x_jk) from the raw features, lane = row, the column
-                // point's features at a uniform address (bit-identical with gram_rbf_kernel)
-                const int gi = i0 + lane;
-                double xi[4 * KR];
-#pragma unroll
-                for (int k = 0; k < 4 * KR; ++k) xi[k] = (k < d) ? Xr[min(gi, nr - 1) + (size_t)k * ldxr] : 0.0;
-                for (int jl = 16 * cbs; jl < 16 * cbe; ++jl) {
-                    const int gj = j0 + jl;
-                    const double *xc = Xc + min(gj, nc - 1);
-                    double r2 = 0.0;
-#pragma unroll
-                    for (int k = 0; k < 4 * KR; ++k)
-                        if (k < d) {
-                            const double diff = xi[k] - xc[(size_t)k * ldxc];
-                            r2 = fma(diff * prm.inv_ls2[k], diff, r2);
-                        }
-                    double v = prm.sf2 * exp(-0.5 * r2);
-                    if (MODE && gi == gj) v = dval;
-                    if (gi < nr && gj < nc && !(diag && gi < gj)) K[gi + (size_t)gj * ldk] = v;
-                    if (MODE == 2 && gi < nr && gj < nc && (!diag || gi > gj)) K[gj + (size_t)gi * ldk] = v;
-                }
-                continue;
-            }
             const bool plain = !diag && i0 + 64 <= nr && j0 + 64 <= nc && (MODE != 2 || (ldk & 3) == 0);
 #pragma unroll
             for (int cb = 0; cb < 4; ++cb) {
@@ -494,16 +489,25 @@ static int gram_form(int d, const GramParams &p, int ldk) {
 
 // `upw` units per wave: about 1.5 waves per resident slot (2 waves per SIMD at this register count), at most 32 -- wave counts that
 // are a multiple of the 2048 slots run in lock step (all load, then all store) and measure up to 25 % slower
+static int next_epoch() {
+    static std::atomic<int> e{0};
+    int v = e.fetch_add(1) + 1;
+    return v <= 0 ? (e = 1, 1) : v;     // wraps after 2^31 calls
+}
+
 template <int MODE>
 static void launch_unit(hipStream_t s, const double *Xr, int nr, int ldxr, const double *Xc, int nc, int ldxc, int d, const GramParams &p,
-                        const double *cen, int ldcen, double *K, int ldk) {
+                        const double *cen, int ldcen, double *K, int ldk, int *far_flag, int epoch) {
+    // the scan: row points and, for the cross form, column points
+    hipLaunchKernelGGL(gram_far_kernel, dim3((nr + (MODE ? 0 : nc) + 255) / 256), dim3(256), 0, s, Xr, nr, ldxr, Xc, MODE ? 0 : nc, ldxc, d, p, cen, ldcen,
+                       far_flag, epoch);
     const int nbr = (nr + 63) / 64, nbc = (nc + 63) / 64;
     const long total = MODE ? 2L * nbr * (nbr + 1) : 4L * nbr * nbc;
     long upw = (total + 3071) / 3072;
     if (upw > 32) upw = 32;
     if (const char *e = getenv("GPCORE_GRAM_UPW")) upw = atoi(e) > 0 ? atoi(e) : upw;
     const unsigned grid = (unsigned)((total + upw - 1) / upw);
-#define GU_LAUNCH(KS, KR) hipLaunchKernelGGL((gram_unit_kernel<KS, KR, MODE>), dim3(grid), dim3(64), 0, s, Xr, nr, ldxr, Xc, nc, ldxc, d, p, cen, ldcen, K, ldk, nbc, (int)upw, total)
+#define GU_LAUNCH(KS, KR) hipLaunchKernelGGL((gram_unit_kernel<KS, KR, MODE>), dim3(grid), dim3(64), 0, s, Xr, nr, ldxr, Xc, nc, ldxc, d, p, cen, ldcen, K, ldk, nbc, (int)upw, total, far_flag, epoch)
     if (d <= 2) GU_LAUNCH(1, 1);
     else if (d <= 4) GU_LAUNCH(2, 1);
     else if (d <= 6) GU_LAUNCH(2, 2);
@@ -514,13 +518,15 @@ static void launch_unit(hipStream_t s, const double *Xr, int nr, int ldxr, const
 #undef GU_LAUNCH
 }
 
-void gpk_gram_sym(hipStream_t s, const double *X, int n, int d, int ldx, const double *theta, double *K, int ldk, int full, double extra_diag) {
+void gpk_gram_sym(hipStream_t s, const double *X, int n, int d, int ldx, const double *theta, double *K, int ldk, int full, double extra_diag, int *far_flag) {
     GramParams p = make_params(theta, d, extra_diag);
     int nb = (n + GT - 1) / GT;
-    const int form = gram_form(d, p, ldk);
+    const int form = far_flag ? gram_form(d, p, ldk) : 0;
     if (form == 2) {
-        if (full) launch_unit<2>(s, X, n, ldx, X, n, ldx, d, p, X, ldx, K, ldk);
-        else launch_unit<1>(s, X, n, ldx, X, n, ldx, d, p, X, ldx, K, ldk);
+        const int epoch = next_epoch();
+        if (full) launch_unit<2>(s, X, n, ldx, X, n, ldx, d, p, X, ldx, K, ldk, far_flag, epoch);
+        else launch_unit<1>(s, X, n, ldx, X, n, ldx, d, p, X, ldx, K, ldk, far_flag, epoch);
+        hipLaunchKernelGGL(gram_rbf_kernel<true>, dim3(nb * (nb + 1) / 2), dim3(256), 0, s, X, n, ldx, X, n, ldx, d, p, K, ldk, full, nb, far_flag, epoch);
         return;
     }
     if (form == 1) {
@@ -540,12 +546,14 @@ void gpk_dgram_sym(hipStream_t s, const double *X, int n, int d, int ldx, const 
     hipLaunchKernelGGL((gram_rbf_kernel<true, true>), dim3(nb * (nb + 1) / 2), dim3(256), 0, s, X, n, ldx, X, n, ldx, d, p, D, ldd, 1, nb);
 }
 
-void gpk_gram_cross(hipStream_t s, const double *Xs, int m, int ldxs, const double *X, int n, int ldx, int d, const double *theta, double *Ks, int ldks) {
+void gpk_gram_cross(hipStream_t s, const double *Xs, int m, int ldxs, const double *X, int n, int ldx, int d, const double *theta, double *Ks, int ldks, int *far_flag) {
     GramParams p = make_params(theta, d, 0.0);
     int nbr = (m + GT - 1) / GT, nbc = (n + GT - 1) / GT;
-    const int form = gram_form(d, p, ldks);
+    const int form = far_flag ? gram_form(d, p, ldks) : 0;
     if (form == 2) {          // centre = first TRAINING point for both operands
-        launch_unit<0>(s, Xs, m, ldxs, X, n, ldx, d, p, X, ldx, Ks, ldks);
+        const int epoch = next_epoch();
+        launch_unit<0>(s, Xs, m, ldxs, X, n, ldx, d, p, X, ldx, Ks, ldks, far_flag, epoch);
+        hipLaunchKernelGGL(gram_rbf_kernel<false>, dim3(nbr * nbc), dim3(256), 0, s, Xs, m, ldxs, X, n, ldx, d, p, Ks, ldks, 1, nbr, far_flag, epoch);
         return;
     }
     if (form == 1) {

@@ -75,8 +75,8 @@ def test_gram_forms_matrix_core_and_per_pair(ctx, monkeypatch, force, n, d, m):
 @pytest.mark.parametrize("n,d,m,scale", [(257, 8, 130, 0.35), (200, 3, 70, 0.08), (330, 14, 65, 0.5), (130, 1, 64, 0.01)])
 def test_gram_points_far_from_the_centre_take_the_per_pair_path(ctx, monkeypatch, n, d, m, scale):
     """The default builder for d <= 14 has the exponent on the matrix cores as ln sf^2 - |z_i|^2/2 - |z_j|^2/2 + z_i.z_j, whose absolute
-    error grows with |z|^2 (z = (x - x_0) / l): a wave whose row strip or column tile holds a point with |z|^2 > 64 sums squared
-    differences instead, in the reference's own order.  Short length scales put (nearly) every tile there."""
+    error grows with |z|^2 (z = (x - x_0) / l): a scan in front of it looks for a point with |z|^2 > 64, and if there is one the
+    per-pair kernel launched behind it (the reference's own order) builds the matrix instead.  Short length scales do that."""
     p = _problem(n, d, m, seed=7 * n + d, scale=scale)
     z2 = (((p["X"] - p["X"][0]) / p["theta"][1:d + 1]) ** 2).sum(axis=1)
     assert z2.max() > 64.0
@@ -102,19 +102,15 @@ def test_gram_points_far_from_the_centre_take_the_per_pair_path(ctx, monkeypatch
     Ks = ctx.cross_gram_rbf(p["Xs"], p["X"], p["theta"])
     Kso = orc.gram_cross(p["Xs"], p["X"], p["theta"])
     close(Ks, Kso, np.ones(Kso.shape, dtype=bool))
-    # and the same bits as the per-pair kernel, which these tiles are computed like
+    # and the same bits as the per-pair kernel on its own, because that is what ran
     K = ctx.gram_rbf(p["X"], p["theta"])
     monkeypatch.setenv("GPCORE_GRAM_MFMA", "0")
-    Kp = ctx.gram_rbf(p["X"], p["theta"])
-    far = [b for b in range((n + 63) // 64) if z2[64 * b:64 * b + 64].max() > 64.0]
-    assert far
-    for b in far:
-        assert np.array_equal(K[64 * b:64 * b + 64], Kp[64 * b:64 * b + 64])
+    assert np.array_equal(K, ctx.gram_rbf(p["X"], p["theta"])) and np.array_equal(Ks, ctx.cross_gram_rbf(p["Xs"], p["X"], p["theta"]))
 
 
-def test_gram_outliers_mix_both_paths_in_one_matrix(ctx):
-    """A few far-away points among ordinary ones: their strips / tiles go per-pair, the rest stays on the matrix cores, and the
-    matrix is still exactly symmetric with an exact diagonal (n = 700: 11 strips, jobs that span strip boundaries)."""
+def test_gram_a_few_outliers_switch_the_whole_matrix(ctx, monkeypatch):
+    """A few far-away points among ordinary ones, in X or only among the test points: the scan finds them and the per-pair kernel
+    builds the matrix (same bits as that kernel alone); without them the matrix-core kernel does (different bits, same tolerance)."""
     n, d, m = 700, 8, 300
     p = _problem(n, d, m, seed=99)
     X = p["X"].copy(order="F")
@@ -134,6 +130,13 @@ def test_gram_outliers_mix_both_paths_in_one_matrix(ctx):
     assert np.max(np.abs(Ks[ok] - Kso[ok]) / Kso[ok]) <= TOL_GRAM
     ok = (Kso > 1e-290) & (Kso <= 1e-39)
     assert not ok.any() or np.max(np.abs(Ks[ok] - Kso[ok]) / Kso[ok]) <= 2e-12
+    Kn = ctx.cross_gram_rbf(Xs, p["X"], p["theta"])          # far test points against ordinary training points
+    Kc = ctx.cross_gram_rbf(p["Xs"], p["X"], p["theta"])      # nothing far
+    monkeypatch.setenv("GPCORE_GRAM_MFMA", "0")
+    assert np.array_equal(K, ctx.gram_rbf(X, p["theta"])) and np.array_equal(Ks, ctx.cross_gram_rbf(Xs, X, p["theta"]))
+    assert np.array_equal(Kn, ctx.cross_gram_rbf(Xs, p["X"], p["theta"]))
+    Kcp = ctx.cross_gram_rbf(p["Xs"], p["X"], p["theta"])
+    assert not np.array_equal(Kc, Kcp) and np.max(np.abs(Kc - Kcp) / Kcp) <= TOL_GRAM
 
 
 @pytest.mark.parametrize("upw", ["1", "3", "7", "1000"])
