@@ -301,6 +301,90 @@ __global__ __launch_bounds__(256) void lml_grad_trace_kernel(const double *__res
     if (tid < d + 2) partials[(size_t)blockIdx.x * (d + 2) + tid] = ((wsum[0][tid] + wsum[1][tid]) + wsum[2][tid]) + wsum[3][tid];
 }
 
+// The same sums for d <= 8 (every BASELINE configuration): one feature chunk, so a column's distance, weight and per-feature terms are
+// finished in ONE pass while its differences are still in registers -- no r2[16] / we[16] arrays indexed by a rolled loop (which the
+// compiler turned into a branch per index: 187 branches, 330 register moves), four independent columns in flight.  Same per-lane
+// summation order as the general kernel: the same bits.  Measured at n = 4096 (a worker alone): 88 -> see DESIGN section 5.
+__global__ __launch_bounds__(256) void lml_grad_trace8_kernel(const double *__restrict__ X, int n, int d, int ldx, TraceParams prm,
+                                                              const double *__restrict__ alpha, const double *__restrict__ Kinv,
+                                                              int ldk, double *__restrict__ partials, int ntiles) {
+    __shared__ double xcs[TR_DC][TR_T];
+    __shared__ double acs[TR_T];                 // alpha of the tile's column points
+    __shared__ double wsum[4][TR_DC + 2];
+    const int tid = threadIdx.x, ti = tid & 63, tq = tid >> 6;
+    for (int e = tid; e < 4 * (TR_DC + 2); e += 256) (&wsum[0][0])[e] = 0.0;
+    double inv[TR_DC];
+#pragma unroll
+    for (int k = 0; k < TR_DC; ++k) inv[k] = prm.inv_ls2[k];     // zero beyond d (launcher)
+    // per-LANE running sums over all of this workgroup's tiles; the cross-lane reductions (10 of them, 120 ds_bpermute) happen once
+    double sk[TR_DC], sE = 0.0, tr = 0.0;
+#pragma unroll
+    for (int k = 0; k < TR_DC; ++k) sk[k] = 0.0;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        int bi, bj;
+        tile_lower_tr(t, bi, bj);
+        const int gi = bi * TR_T + ti;
+        const double wgt = (bi == bj) ? 1.0 : 2.0;
+        __syncthreads();
+        for (int e = tid; e < TR_DC * TR_T; e += 256) {
+            const int kk = e >> 6, jj = e & 63, gj = bj * TR_T + jj;
+            xcs[kk][jj] = (gj < n && kk < d) ? X[gj + (size_t)kk * ldx] : 0.0;
+        }
+        if (tid < TR_T) acs[tid] = (bj * TR_T + tid < n) ? alpha[bj * TR_T + tid] : 0.0;
+        double xi[TR_DC];
+#pragma unroll
+        for (int k = 0; k < TR_DC; ++k) xi[k] = (gi < n && k < d) ? X[gi + (size_t)k * ldx] : 0.0;
+        const double ai = (gi < n) ? alpha[gi] : 0.0;
+        // this thread's entries of Kinv four columns at a time, the next four requested before the current four are worked on
+        auto kinv4 = [&](int qc, double (&kv)[4]) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int gj = bj * TR_T + tq + 4 * (4 * qc + u);
+                const int hi = gi > gj ? gi : gj, lo = gi > gj ? gj : gi;
+                kv[u] = (Kinv && gi < n && gj < n) ? Kinv[hi + (size_t)lo * ldk] : 0.0;
+            }
+        };
+        double kcur[4], knext[4];
+        kinv4(0, kcur);
+        __syncthreads();
+#pragma unroll 1
+        for (int qc = 0; qc < 4; ++qc) {
+            if (qc < 3) kinv4(qc + 1, knext);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int jj = tq + 4 * (4 * qc + u), gj = bj * TR_T + jj;
+                double diff[TR_DC], r2 = 0.0;
+#pragma unroll
+                for (int k = 0; k < TR_DC; ++k) {
+                    diff[k] = xi[k] - xcs[k][jj];
+                    r2 = fma(diff[k] * inv[k], diff[k], r2);
+                }
+                double w = 0.0;
+                if (gi < n && gj < n) {
+                    w = ai * acs[jj] - kcur[u];
+                    if (gi == gj) tr += w;
+                }
+                const double we = wgt * w * exp(-0.5 * r2);
+                sE += we;
+#pragma unroll
+                for (int k = 0; k < TR_DC; ++k) sk[k] = fma(we, diff[k] * diff[k], sk[k]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) kcur[u] = knext[u];
+        }
+    }
+    sE = wave_sum(sE);
+    tr = wave_sum(tr);
+    if (ti == 0) { wsum[tq][0] = sE; wsum[tq][d + 1] = tr; }
+#pragma unroll
+    for (int k = 0; k < TR_DC; ++k) {
+        const double tot = wave_sum(sk[k]);
+        if (ti == 0 && k < d) wsum[tq][1 + k] = tot;
+    }
+    __syncthreads();
+    if (tid < d + 2) partials[(size_t)blockIdx.x * (d + 2) + tid] = ((wsum[0][tid] + wsum[1][tid]) + wsum[2][tid]) + wsum[3][tid];
+}
+
 struct TraceScale { double s[TR_DMAX + 2]; };
 __global__ __launch_bounds__(256) void lml_grad_reduce_kernel(const double *__restrict__ partials, int nblocks, int P, TraceScale sc,
                                                               double *__restrict__ out) {
@@ -334,7 +418,7 @@ void gpk_set_identity(hipStream_t s, double *A, int n, int lda) {
 void gpk_set_identity_upper(hipStream_t s, double *A, int n, int lda) {
     hipLaunchKernelGGL(set_identity_upper_kernel, dim3(4, n < 65535 ? n : 65535), dim3(256), 0, s, A, n, lda);
 }
-constexpr int TR_MAX_WG = 1024;   // 4 per CU: enough to hide the Kinv stream, few enough that the fixed-order reduce stays short
+constexpr int TR_MAX_WG = 768;    // what is resident at once (3 workgroups per CU at ~150 registers): 1024 ran as 768 + a second wave of 256, i.e. 4-5 tile times where 3 do (n = 4096: 2080 tiles; 49 -> see DESIGN)
 int gpk_lml_grad_partials_size(int n, int d) {
     (void)n;
     return TR_MAX_WG * (d + 2);
@@ -354,7 +438,10 @@ void gpk_lml_grad_traces(hipStream_t s, const double *X, int n, int d, int ldx, 
     }
     sc.s[d + 1] = sn;
     const int nb = (n + TR_T - 1) / TR_T, ntiles = nb * (nb + 1) / 2, nblocks = ntiles < TR_MAX_WG ? ntiles : TR_MAX_WG;
-    hipLaunchKernelGGL(lml_grad_trace_kernel, dim3(nblocks), dim3(256), 0, s, X, n, d, ldx, prm, alpha, Kinv, ldk, partials, ntiles);
+    const char *ge = getenv("GPCORE_TRACE_GENERAL");       // tests: the d > 8 kernel at d <= 8 (read per call)
+    const bool general = ge && atoi(ge) != 0;
+    if (d <= TR_DC && !general) hipLaunchKernelGGL(lml_grad_trace8_kernel, dim3(nblocks), dim3(256), 0, s, X, n, d, ldx, prm, alpha, Kinv, ldk, partials, ntiles);
+    else hipLaunchKernelGGL(lml_grad_trace_kernel, dim3(nblocks), dim3(256), 0, s, X, n, d, ldx, prm, alpha, Kinv, ldk, partials, ntiles);
     hipLaunchKernelGGL(lml_grad_reduce_kernel, dim3(d + 2), dim3(256), 0, s, partials, nblocks, d + 2, sc, out);
 }
 

@@ -766,6 +766,20 @@ def test_strided_views_through_the_c_abi(ctx):
     ctx._lib.gp_model_destroy(h)
 
 
+@pytest.mark.parametrize("n,d", [(300, 8), (257, 3), (130, 1)])
+def test_lml_gradient_traces_small_d_kernel_agrees_with_the_general_kernel(ctx, monkeypatch, n, d):
+    """d <= 8 has its own trace kernel (one pass per column, everything in registers, per-lane sums over all tiles of a workgroup);
+    the same terms as the general one in another order of summation: equal to rounding."""
+    p = _problem(n, d, 0, seed=3 * n + d)
+    thetas = np.stack([p["theta"], p["theta"] * 1.2])
+    l1, g1, _ = ctx.lml_grad_batched(p["X"], p["y"], thetas)
+    monkeypatch.setenv("GPCORE_TRACE_GENERAL", "1")
+    l2, g2, _ = ctx.lml_grad_batched(p["X"], p["y"], thetas)
+    assert np.array_equal(l1, l2) and np.max(np.abs(g1 - g2)) <= 1e-12 * np.max(np.abs(g2))
+    ol, og = orc.lml_grad(p["X"], p["y"], thetas[1])
+    assert np.max(np.abs(g1[1] - og)) <= 1e-8 * np.max(np.abs(og))
+
+
 def test_ill_conditioned_but_pd_problem(ctx):
     """Tiny noise, long length-scales: kappa(K) ~ 1e9.  The factorisation residual must stay at the rounding level and
     downstream quantities agree with the oracle to the tolerance its conditioning allows."""
