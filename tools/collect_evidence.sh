@@ -4,7 +4,7 @@
 # throughput.  usage (from the repo root on the box): bash tools/collect_evidence.sh <tag> [quick|full] [first stage: 0 bench lines, 1 pmc c2/c3, 2 pmc c4/c5, 3 the rest]
 # Every step appends to $O/progress.log so that a long collection never looks hung.
 set -o pipefail
-TAG=${1:-r03_z}
+TAG=${1:-r03_final}
 QUICK=${2:-}
 FROM=${3:-0}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
