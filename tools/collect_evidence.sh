@@ -16,7 +16,7 @@ pmc() {   # pmc <name> <bench args...>: FETCH / WRITE / MFMA-busy passes of one 
     local name=$1; shift
     for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
         local tagset=$(echo $set | cut -d' ' -f1)
-        timeout -k 10 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/pmc_${name}_$tagset -o p -- python3 $R/bench.py "$@" > $O/pmc_${name}_$tagset.log 2>&1 && say "pmc $name $tagset ok"
+        timeout -k 10 120 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/pmc_${name}_$tagset -o p -- python3 $R/bench.py "$@" > $O/pmc_${name}_$tagset.log 2>&1 && say "pmc $name $tagset ok"
     done
     python3 $R/tools/pmc_summary.py $O/pmc_${name}_summary.json "rocprofv3 --kernel-trace --pmc <set> --output-format csv -- python3 bench.py $*; one counter set per run (FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE)" $(find $O/pmc_${name}_* -name "*counter_collection.csv") > $O/pmc_${name}_summary.txt 2>&1 && say "pmc $name summary ok"
     rm -rf $O/pmc_${name}_FETCH_SIZE $O/pmc_${name}_WRITE_SIZE $O/pmc_${name}_SQ_VALU_MFMA_BUSY_CYCLES
