@@ -231,7 +231,8 @@ __global__ __launch_bounds__(256) void gram_mfma_kernel(const double *__restrict
 // own order -- builds it otherwise; the half that is not needed returns at its first instruction.  No host round trip, and wide
 // data costs what it cost in rounds 1-2.  (A per-tile choice inside this kernel was tried first: one wave per 64 x 64 tile on the
 // vector unit runs at a third of gram_rbf_kernel's speed -- profiles/r03_h_gram_scales.log.)
-// Measured at n = 8192, m = 65536, d = 8 (lab): lower 84 -> 59 us (4.6 TB/s), mirrored 121 -> 110 us, cross 1.17 -> 0.86 ms (5.0 TB/s).
+// Measured at n = 8192, m = 65536, d = 8, as called (scan + kernel + empty launch): lower 84 -> 61 us (4.4 TB/s; 57 us the kernel alone),
+// mirrored 124 -> 123 us, cross 1.12 -> 0.84 ms (5.1 TB/s); by feature count profiles/r03_l_gram_by_d.log.
 constexpr double GRAM_NORM_LIMIT = 64.0;
 constexpr int GU_DMAX = 14;
 
@@ -322,8 +323,7 @@ __global__ __launch_bounds__(64) void gram_unit_kernel(const double *__restrict_
     }
     const double lnsf2 = prm.lnsf2, dval = (prm.sf2 + prm.sn2) + prm.extra;
     constexpr int JS = (MODE == 2) ? 1 : 4;      // column step between a lane's four accumulator registers
-    // lane parts of the store addresses as 32-bit byte offsets (ldk < 2^25, launcher): uniform base + zext(offset) is the scalar-base
-    // form of global_store, no vector address arithmetic per store
+    // lane parts of the store addresses as 32-bit byte offsets (ldk < 2^25, launcher) on top of a uniform base per block
     const unsigned voff = ((unsigned)fr + (unsigned)((MODE == 2) ? 4 * fk : fk) * (unsigned)ldk) * 8u;    // primary store
     const unsigned moff = ((unsigned)(4 * fk) + (unsigned)fr * (unsigned)ldk) * 8u;                        // mirrored store
     double zr[4][KS], zc[4][KS], raw[4][KR];
