@@ -353,7 +353,7 @@ def test_fit_errors_match_reference_conventions(ctx):
 
 
 # ---- LML gradient (GpPredictor.logLikelihoodWithDerivatives) ------------------------------------
-@pytest.mark.parametrize("n,d", [(60, 1), (200, 3), (333, 8)])
+@pytest.mark.parametrize("n,d", [(60, 1), (200, 3), (333, 8), (200, 9), (257, 13), (150, 20)])   # d > 8: the general trace kernel, 2-3 feature chunks
 def test_lml_grad_vs_oracle(ctx, n, d):
     p = _problem(n, d, 0, seed=n)
     th2 = p["theta"] * np.concatenate(([1.4], np.linspace(0.7, 1.9, d), [2.0]))
