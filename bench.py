@@ -35,6 +35,16 @@ PEAK_FP64_MFMA_TFLOPS = 78.6   # MI355X vendor fp64 matrix peak; 
 PEAK_HBM_GBS = 8000.0
 
 
+def progress(msg):
+    """One line on stderr when GPCORE_BENCH_PROGRESS is set: under a profiler that may stop the program (a PMC pass cut by its time
+    limit leaves no trace of how far the program got) the log then says where."""
+    if os.environ.get("GPCORE_BENCH_PROGRESS"):
+        print("[bench %.1fs] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
+
+
+_T0 = time.perf_counter()
+
+
 def host_cores():
     """Cores this process may really use: the affinity mask, cut by a cgroup CPU quota when there is one (the GPU box hands a
     16-core share of a 256-thread host: spawning one BLAS thread per visible CPU only oversubscribes it)."""
@@ -48,16 +58,17 @@ def host_cores():
     return max(1, min(n, int(os.environ.get("GPCORE_CPU_THREADS", "64"))))
 
 
-def cpu_baseline(p, L_host, alpha_host, m_total, budget_pts=256, fit_full_size=False):
+def cpu_baseline(p, L_host, alpha_host, m_total, predict_pts=32, fit_full_size=False):
     """The stated CPU baseline (`cpu_ref`): oracle/gp_oracle.c -- the 1-thread restatement of the reference's
     loops -- timed on a BOUNDED sample of the same workload.  Fit (Gram + unblocked Cholesky + two substitution solves,
-    GpPredictor.preComputeComponents) is timed at n = 1024, 2048, 4096 on leading subsets of the same X, y and extrapolated
-    to the full n by the power law through the last two sizes, t(n) = t(4096) (n / 4096)^p with p = log2(t(4096) / t(2048))
-    -- the measured exponent, printed in the record: the row-walking substitution and the unblocked Cholesky fall out of
-    cache as n grows, so the growth per doubling is well above the 8x of a cubic (7x then 13x measured) and a cubic fit
-    would understate n = 8192.  `--cpu-fit-full` times the fit at the full n instead (about a minute).  Predict (cross-Gram +
-    scalar forward substitution + variance per point) is timed at the full n against the real factor on a few of the test
-    points.  value = points/s of a whole fit + predict step, the benchmark's metric."""
+    GpPredictor.preComputeComponents) is timed at n = 1024, 2048, 4096 on leading subsets of the same X, y and extrapolated to
+    the full n by the power law fitted through ALL THREE sizes (least squares in log-log; the exponent of the last doubling alone
+    is printed beside it: the row-walking substitution and the unblocked Cholesky fall out of cache as n grows, so the growth per
+    doubling rises -- 7x then 13x measured -- and the two exponents bracket n = 8192).  `--cpu-fit-full` times the fit at the
+    full n instead (about a minute).  Predict (cross-Gram + scalar forward substitution + variance per point) is timed at the
+    full n against the real factor on `predict_pts` = 32 of the test points (about 1.7 s each: the substitution walks the rows of a
+    column-major 8192 x 8192 factor).  value = points/s of a whole fit + predict step, the benchmark's metric; the predict term
+    is 99.9 % of it."""
     from oracle import gp_oracle as orc
     orc.build()
     n = p["X"].shape[0]
@@ -70,29 +81,31 @@ def cpu_baseline(p, L_host, alpha_host, m_total, budget_pts=256, fit_full_size=F
         t0 = time.perf_counter()
         orc.fit(Xs_, ys_, p["theta"])
         fit_s.append(time.perf_counter() - t0)
-    expo = float(np.log(fit_s[-1] / fit_s[-2]) / np.log(sizes[-1] / sizes[-2])) if len(sizes) >= 2 else 3.0
+    expo_last = float(np.log(fit_s[-1] / fit_s[-2]) / np.log(sizes[-1] / sizes[-2])) if len(sizes) >= 2 else 3.0
+    if len(sizes) >= 3:
+        expo, icpt = (float(v) for v in np.polyfit(np.log(sizes[-3:]), np.log(fit_s[-3:]), 1))
+    else:
+        expo, icpt = expo_last, float(np.log(fit_s[-1]) - expo_last * np.log(sizes[-1]))
     if sizes and sizes[-1] == n:
         fit_full, extrapolated = fit_s[-1], False
     else:
-        fit_full, extrapolated = float(fit_s[-1] * (float(n) / sizes[-1]) ** expo), True
-    xs = np.asfortranarray(p["Xs"][:2])
-    t0 = time.perf_counter()
-    orc.predict(p["X"], p["theta"], L_host, alpha_host, xs)
-    per_pt = (time.perf_counter() - t0) / 2
-    k = int(max(2, min(budget_pts, 10.0 / max(per_pt, 1e-6))))
+        fit_full, extrapolated = float(np.exp(icpt + expo * np.log(float(n)))), True
+    k = int(max(2, min(predict_pts, p["Xs"].shape[0])))
     xs = np.asfortranarray(p["Xs"][:k])
     t0 = time.perf_counter()
     mean, var, _, _ = orc.predict(p["X"], p["theta"], L_host, alpha_host, xs)
     dt = time.perf_counter() - t0
     step_s = fit_full + m_total * dt / k
     return dict(value=m_total / step_s, unit="points/s", cores=1, kind="port", extrapolated=extrapolated,
-                fit_s_measured={str(s_): t for s_, t in zip(sizes, fit_s)}, fit_growth_exponent_last_doubling=expo,
-                fit_s_at_n=fit_full, predict_points_per_s=k / dt, step_s_at_n=step_s,
+                fit_s_measured={str(s_): t for s_, t in zip(sizes, fit_s)}, fit_growth_exponent_three_sizes=expo,
+                fit_growth_exponent_last_doubling=expo_last,
+                fit_s_at_n=fit_full, predict_points_per_s=k / dt, predict_points_timed=k, step_s_at_n=step_s,
                 sample="oracle/gp_oracle.c, 1 thread: fit timed at n=%s on leading subsets of the same X, y%s; predict timed on %d of "
                        "the %d test points at the full n=%d against the factor of the GPU fit; value = %d points / (fit + %d "
                        "points at the measured rate)"
                        % ("/".join(map(str, sizes)),
-                          " and extrapolated to n=%d by the power law through the last two sizes (exponent %.2f)" % (n, expo)
+                          " and extrapolated to n=%d by the power law fitted through the three sizes (exponent %.2f; last doubling "
+                          "alone %.2f)" % (n, expo, expo_last)
                           if extrapolated else " (the full n included: nothing extrapolated)",
                           k, m_total, n, m_total, m_total)), mean, var, k
 
@@ -203,6 +216,7 @@ def run_secondary(args):
     if args.workload == "c3":
         n = args.n if args.n != 8192 else 4096
         c3 = measure_c3(ctx, n, args.d, args.steps, args.warmup, rank, world, local_rank, backend, coll_dev, names)
+        xin = c3.pop("_cross_check_inputs")
         if rank == 0:
             P, B = args.d + 2, c3["B"]
             print(json.dumps({"metric": "LML+gradient settings/sec at n=%d fp64, P=%d" % (n, P), "value": c3["settings_per_s"],
@@ -217,6 +231,8 @@ def run_secondary(args):
                               "lml_first": c3["lml_first"], "lml_last": c3["lml_last"], "all_finite": c3["all_finite"],
                               "lockstep_vs_single_setting_max_rel": c3["lockstep_vs_single_setting_max_rel"],
                               "c_abi_rccl_allgather_matches": c3["c_abi_rccl_allgather_matches"]}), flush=True)
+        c3["_cross_check_inputs"] = xin
+        c_abi_cross_check(ctx, c3, rank, world, local_rank, backend)      # after the line: cannot cost it
     elif args.workload == "c5":
         import ctypes as C
         n = args.n if args.n != 8192 else 32768
@@ -280,13 +296,18 @@ def run_secondary(args):
         n = args.n if args.n != 8192 else 4096
         sweeps = 50
         p = synth.config_c4(n, args.d)
+        progress("c4: context up, building the Gram matrix")
         K = ctx.gram_rbf(p["X"], p["theta"], full=True)
+        progress("c4: Gram matrix built (mirrored form), creating the EP state")
         ep = EpClassifierState(ctx, K, p["y"])
+        progress("c4: EP state created, first sweep")
         ep.sweep(1)
         fence()
+        progress("c4: warm-up sweep done, timed sweeps")
         t0 = time.perf_counter()
         for _ in range(args.steps):
             tau, nu = ep.sweep(sweeps)
+            progress("c4: %d sweeps done" % sweeps)
         fence()
         dt = gdist.max_over_ranks(time.perf_counter() - t0, device=coll_dev)
         # the roofline block's HIP events (two per launch of the profiled classes, on four streams) cost this latency-bound workload
@@ -295,6 +316,7 @@ def run_secondary(args):
         ep.sweep(sweeps)
         fence()
         ctx.profile(0)
+        progress("c4: profiled sweeps done")
         names_c4 = dict(names)
         names_c4[L.GP_PROF_SYRK] = ("gemm_nt_f64_kernel<1,*> / gemm_k128_kernel<1> (lower-trapezoid products of the refactorisation that runs under "
                                     "the site loop: K = 512 trailing updates, next covariance -= Vt Vt^T; launched on two side streams, so a "
@@ -395,23 +417,6 @@ def measure_c3(ctx, n, d, steps, warmup, rank, world, local_rank, backend, coll_
     b0 = lo if hi > lo else 0
     one, gone, _ = ctx.lml_grad_batched(p["X"], p["y"], p["thetas"][b0:b0 + 1])
     chk = float(max(abs(one[0] - lml[b0]) / abs(one[0]), np.max(np.abs(gone[0] - grad[b0])) / np.max(np.abs(gone[0]))))
-    cabi = None
-    if world > 1 and backend == "nccl":
-        try:
-            import torch.distributed as tdist
-            from gp_algos_amd.core import DistGroup
-
-            def exchange(ident):
-                obj = [ident]
-                tdist.broadcast_object_list(obj, src=0, device=torch.device("cuda", local_rank))
-                return obj[0]
-
-            grp = DistGroup(ctx, rank, world, exchange)
-            l2, g2, _ = grp.lml_grad_batched(p["X"], p["y"], p["thetas"])
-            cabi = bool(np.array_equal(l2, lml) and np.array_equal(g2, grad))
-            grp.close()
-        except Exception as e:   # reported, never fatal for the benchmark line
-            cabi = "failed: %s" % e
     # n^3/3 (potrf) + 2 n^3/3 (K^-1 from L) + 2 n^2 (alpha) + P 2 n^2 (fused traces) per setting
     flops = float(n) ** 3 + (2.0 + 2.0 * P) * n * n
     tf = flops * B * steps / dt / 1e12
@@ -425,7 +430,62 @@ def measure_c3(ctx, n, d, steps, warmup, rank, world, local_rank, backend, coll_
             "frac_of_fp64_mfma_peak_per_gpu": tf / world / PEAK_FP64_MFMA_TFLOPS, "roofline": roof,
             "per_rank_seconds": [float(t) for t in times[:, 0]], "lml_first": float(lml[0]), "lml_last": float(lml[-1]),
             "all_finite": bool(np.all(np.isfinite(lml)) and np.all(np.isfinite(grad))),
-            "lockstep_vs_single_setting_max_rel": chk, "c_abi_rccl_allgather_matches": cabi}
+            "lockstep_vs_single_setting_max_rel": chk,
+            "c_abi_rccl_allgather_matches": ("checked AFTER this line is printed (c_abi_cross_check); result as one JSON line on stderr"
+                                             if world > 1 and backend == "nccl" else None),
+            "_cross_check_inputs": (p, lml, grad)}
+
+
+def c_abi_cross_check(ctx, c3, rank, world, local_rank, backend):
+    """The C3 evaluation once more through the C-ABI's own RCCL path (gp_dist_unique_id -> gp_dist_init -> gp_dist_lml_grad_batched:
+    what a Scala host calls), compared bit for bit with the torch.distributed result.  Runs AFTER rank 0 has printed and flushed the
+    benchmark line, so nothing that goes wrong here can cost the line; its result goes to stderr as one JSON
+    line.  A failure on ONE rank before the communicator exists must not strand the others inside ncclCommInitRank: every local
+    step is followed by a torch all_reduce(MIN) of "this rank is fine", and all ranks skip together when any rank is not."""
+    import torch
+    import torch.distributed as tdist
+    from gp_algos_amd import _lib as L
+    if not (world > 1 and backend == "nccl" and c3 is not None):
+        return None
+    p, lml, grad = c3["_cross_check_inputs"]
+    lib = ctx._lib
+    dev = torch.device("cuda", local_rank)
+
+    def everybody(ok):
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        tdist.all_reduce(t, op=tdist.ReduceOp.MIN)
+        return bool(t.item())
+
+    result, h = None, C.c_void_p()
+    try:
+        buf = C.create_string_buffer(L.GP_DIST_ID_BYTES)
+        st = lib.gp_dist_unique_id(ctx.h, buf)          # every rank: resolves RCCL here (only rank 0's id is used)
+        if not everybody(st == 0):
+            result = "skipped: RCCL could not be resolved on some rank (this rank: status %d %s)" % (st, lib.gp_last_error(ctx.h).decode() if st else "")
+        else:
+            ident = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).to(dev)
+            tdist.broadcast(ident, src=0)               # a plain byte tensor: nothing is pickled
+            raw = bytes(ident.cpu().numpy().tobytes())
+            st = lib.gp_dist_init(ctx.h, C.create_string_buffer(raw, L.GP_DIST_ID_BYTES), rank, world, C.byref(h))
+            if not everybody(st == 0):
+                result = "skipped: gp_dist_init failed on some rank (this rank: status %d %s)" % (st, lib.gp_last_error(ctx.h).decode() if st else "")
+            else:
+                from gp_algos_amd.core import DistGroup
+                grp = DistGroup.__new__(DistGroup)
+                grp.ctx, grp.rank, grp.world, grp.h = ctx, rank, world, h
+                h = C.c_void_p()
+                l2, g2, _ = grp.lml_grad_batched(p["X"], p["y"], p["thetas"])
+                result = bool(np.array_equal(l2, lml) and np.array_equal(g2, grad))
+                grp.close()
+    except Exception as e:                              # reported, never fatal
+        result = "failed: %s" % e
+    if h.value:
+        lib.gp_dist_destroy(h)
+    if rank == 0:
+        print(json.dumps({"c_abi_rccl_allgather_matches": result, "n_gpus": world,
+                          "librccl_mapped": sorted({ln.split()[-1] for ln in open("/proc/self/maps") if "librccl" in ln})}),
+              file=sys.stderr, flush=True)
+    return result
 
 
 def self_launch(gpus, argv, dry=False):
@@ -639,6 +699,25 @@ def main():
     ctx.sync()
     t_pred = time.perf_counter() - t1
     ctx.check(lib.gp_model_status(h, C.byref(info)), info.value)
+    # End to end as SURVEY.md 8(d) "GPU timing" asks: one step INCLUDING the transfers -- H2D of X, y and X* (pageable host arrays,
+    # as a JNI caller hands them over), refit, predict, D2H of mean and variance.  Reported beside `value`, never as `value`.
+    hX, hy, hXs = np.asfortranarray(p["X"]), np.ascontiguousarray(p["y"]), np.asfortranarray(p["Xs"])
+    hmean, hvar = np.empty(m), np.empty(m)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    e2e = []
+    for _ in range(3):
+        ctx.sync()
+        t1 = time.perf_counter()
+        ctx.check(lib.gp_dev_upload(ctx.h, dX, vp(hX), hX.nbytes))
+        ctx.check(lib.gp_dev_upload(ctx.h, dy, vp(hy), hy.nbytes))
+        ctx.check(lib.gp_dev_upload(ctx.h, dXs, vp(hXs), hXs.nbytes))
+        ctx.check(lib.gp_model_refit_dev(h, L.dptr(theta), nan))
+        ctx.check(lib.gp_predict_dev(h, dXs, m, m, dmean, dvar))
+        ctx.check(lib.gp_dev_download(ctx.h, vp(hmean), dmean, hmean.nbytes))
+        ctx.check(lib.gp_dev_download(ctx.h, vp(hvar), dvar, hvar.nbytes))
+        ctx.sync()
+        e2e.append(time.perf_counter() - t1)
+    t_e2e = sorted(e2e)[1]
     # The trailing-update kernels by themselves: one refit with the look-ahead off (overlapping launches would each be timed
     # with the other running beside them), HIP events around every launch of the two classes
     ctx.check(lib.gp_ctx_set_lookahead(ctx.h, 0))
@@ -653,10 +732,11 @@ def main():
     p_k, p_ms, p_work = ctx.profile_read(L.GP_PROF_PANEL_UPD)
 
     # The north-star's scaling workload in the same line: C3 sharded over the ranks (every rank takes part: collectives inside)
-    c3 = None
+    c3, c3_inputs = None, None
     if not args.no_c3:
         c3 = measure_c3(ctx, 4096, d, max(2, min(args.steps, 5)), 1, rank, world, local_rank, backend,
                         "cuda" if backend == "nccl" else "cpu", _class_names(L))
+        c3_inputs = c3.pop("_cross_check_inputs")
 
     out = None
     if rank == 0:
@@ -701,6 +781,10 @@ def main():
             "cholesky": _cholesky_block(n, t_fit, t_fit_serial, o_k, o_ms, o_work, p_k, p_ms, p_work),
             "gram": {"GBps": r_work / (r_ms * 1e-3) / 1e9 if r_ms > 0 else 0.0, "frac_of_hbm_peak": (r_work / (r_ms * 1e-3) / 1e9) / PEAK_HBM_GBS if r_ms > 0 else 0.0},
             "predict_only_points_per_s": m / t_pred, "predict_ms": t_pred * 1e3,
+            "e2e_ms_per_step": t_e2e * 1e3, "e2e_points_per_s": m / t_e2e,
+            "e2e_note": "one step INCLUDING transfers (SURVEY.md 8(d) GPU timing): H2D of X, y, X* (%.1f MB, pageable host memory) + refit + "
+                        "predict + D2H of mean and variance (%.1f MB); median of 3; rank 0's GPU only, not part of `value`"
+                        % ((hX.nbytes + hy.nbytes + hXs.nbytes) / 1e6, 2 * hmean.nbytes / 1e6),
             "mfma_f64_probe_tflops": probe,
             "c3_sharded": c3,
         }
@@ -725,6 +809,10 @@ def main():
         out["cpu_opt_baseline"] = opt
     if rank == 0:
         print(json.dumps(out), flush=True)
+    if c3 is not None and c3_inputs is not None:
+        # only now, with the line out: the C-ABI's own RCCL path against the torch.distributed result (stderr)
+        c3["_cross_check_inputs"] = c3_inputs
+        c_abi_cross_check(ctx, c3, rank, world, local_rank, backend)
     lib.gp_model_destroy(h)
     ctx.close()
     if world > 1:

@@ -749,6 +749,9 @@ void gp_ctx_destroy(gp_ctx *ctx) {
     for (int i = 0; i < WS_COUNT; ++i) if (x->ws[i].p) (void)hipFree(x->ws[i].p);
     if (ctx->d_scalars) (void)hipFree(ctx->d_scalars);
     if (ctx->d_info) (void)hipFree(ctx->d_info);
+    if (ctx->d_cflags) (void)hipFree(ctx->d_cflags);
+    for (hipEvent_t e : ctx->chol_ev) (void)hipEventDestroy(e);
+    ctx->chol_ev.clear();
     if (ctx->ev_a) (void)hipEventDestroy(ctx->ev_a);
     if (ctx->ev_b) (void)hipEventDestroy(ctx->ev_b);
     if (ctx->side) (void)hipStreamDestroy(ctx->side);

@@ -204,18 +204,25 @@ gp_status gp_dist_shard(const gp_dist *d, int total, int *lo, int *hi) {
 
 gp_status gp_dist_lml_grad_batched(gp_dist *d, const double *X, int n, int dd, int ldx, const double *y, const double *thetas, int B,
                                    int nparams, double sigma_noise, double *lml, double *grad, int *info) {
-    if (!d) return GP_EINVAL;
+    if (!d) return GP_EINVAL;   // no communicator: nothing to exchange a status over
     gp_ctx *ctx = d->ctx;
-    GP_REQUIRE(ctx, X && y && thetas && lml && B >= 0 && nparams >= 0 && (nparams == 0 || grad), "bad arguments");
-    if (B == 0) return GP_OK;
-    const int P = dd + 2, per = (B + d->world - 1) / d->world;
+    // Nothing between here and dist_agree returns.  A rank that fails locally -- a bad argument only it sees included -- still
+    // takes part in the status exchange: its peers are already on their way into that all-gather.  (B and nparams size the
+    // exchange itself, so the ranks must agree on them like on the communicator; a rank that disagrees is caught by RCCL.)
+    gp_status local = GP_OK;
+    if (!(X && y && thetas && lml && B >= 0 && nparams >= 0 && (nparams == 0 || grad))) {
+        GP_SET_ERR(ctx, "invalid argument: bad arguments");
+        local = GP_EINVAL;
+    }
+    const int Bs = std::max(B, 0), NPs = std::max(nparams, 0);
+    if (local == GP_OK && B == 0) return GP_OK;   // an empty batch is empty on every rank: no collective at all
+    const int P = dd + 2, per = (Bs + d->world - 1) / d->world;
     int lo = 0, hi = 0;
-    GP_TRY(gp_dist_shard(d, B, &lo, &hi));
-    const int mine = hi - lo, W = 2 + nparams;   // per setting: lml | info | grad[nparams]
-    std::vector<double> l(std::max(mine, 1)), g((size_t)std::max(mine, 1) * std::max(nparams, 1));
+    if (gp_dist_shard(d, Bs, &lo, &hi) != GP_OK) lo = hi = 0;
+    const int mine = hi - lo, W = 2 + NPs;   // per setting: lml | info | grad[nparams]
+    std::vector<double> l(std::max(mine, 1)), g((size_t)std::max(mine, 1) * std::max(NPs, 1));
     std::vector<int> inf(std::max(mine, 1), 0);
-    // nothing between here and dist_agree returns: a rank that fails locally still takes part in the status exchange
-    gp_status local = dist_reserve(d, (size_t)per * (2 + nparams));
+    if (local == GP_OK) local = dist_reserve(d, (size_t)per * (2 + NPs));
     if (local == GP_OK && mine > 0)
         local = gp_lml_grad_rbf_batched(ctx, X, n, dd, ldx, y, thetas + (size_t)lo * P, mine, nparams, sigma_noise, l.data(), g.data(), inf.data());
     if (local == GP_OK && d->fail_next) local = GP_ENOMEM, d->fail_next = 0;
@@ -238,17 +245,24 @@ gp_status gp_dist_lml_grad_batched(gp_dist *d, const double *X, int n, int dd, i
 }
 
 gp_status gp_dist_predict(gp_dist *d, gp_model *model, const double *Xs, int m, int ldxs, double *mean, double *var) {
-    if (!d || !model) return GP_EINVAL;
+    if (!d) return GP_EINVAL;   // no communicator: nothing to exchange a status over
     gp_ctx *ctx = d->ctx;
-    GP_REQUIRE(ctx, Xs && mean && var && m >= 0 && ldxs >= m, "bad arguments");
-    GP_REQUIRE(ctx, model->ctx == ctx, "the model must live on the context the communicator was created on");
-    if (m == 0) return GP_OK;
-    const int per = (m + d->world - 1) / d->world;
+    // as above: every local check feeds the status exchange instead of returning ahead of it
+    gp_status local = GP_OK;
+    if (!(model && Xs && mean && var && m >= 0 && ldxs >= m)) {
+        GP_SET_ERR(ctx, "invalid argument: bad arguments");
+        local = GP_EINVAL;
+    } else if (model->ctx != ctx) {
+        GP_SET_ERR(ctx, "invalid argument: the model must live on the context the communicator was created on");
+        local = GP_EINVAL;
+    }
+    if (local == GP_OK && m == 0) return GP_OK;   // an empty request is empty on every rank
+    const int ms = std::max(m, 0), per = (ms + d->world - 1) / d->world;
     int lo = 0, hi = 0;
-    GP_TRY(gp_dist_shard(d, m, &lo, &hi));
+    if (gp_dist_shard(d, ms, &lo, &hi) != GP_OK) lo = hi = 0;
     const int mine = hi - lo;
     std::vector<double> pack((size_t)2 * std::max(mine, 1), 0.0), all;
-    gp_status local = dist_reserve(d, (size_t)2 * per);
+    if (local == GP_OK) local = dist_reserve(d, (size_t)2 * per);
     if (local == GP_OK && mine > 0) local = gp_predict(model, Xs + lo, mine, ldxs, pack.data(), pack.data() + mine, nullptr, 0);
     if (local == GP_OK && d->fail_next) local = GP_ENOMEM, d->fail_next = 0;
     GP_TRY(dist_agree(d, local));

@@ -7,6 +7,8 @@ import os
 
 import numpy as np
 
+from . import _lib
+
 
 def env_rank_world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
@@ -52,12 +54,14 @@ def max_over_ranks(value, device="cpu"):
     return float(t.item())
 
 
-class PeerFailure(RuntimeError):
-    """Another rank's local evaluation failed; nothing was exchanged (the torch.distributed form of GP_EPEER)."""
+class PeerFailure(_lib.PeerFailure):
+    """Another rank's local evaluation failed; nothing was exchanged (the torch.distributed form of GP_EPEER).  A subclass of the
+    exception the C-ABI path raises for GP_EPEER (`_lib.PeerFailure`, itself a `GpCoreError`), so `except _lib.PeerFailure` catches
+    a peer failure whichever of the two exchanges reported it."""
 
     def __init__(self, bad_rank, status):
-        super().__init__("rank %d of the group failed with status %d; no result was exchanged" % (bad_rank, status))
-        self.bad_rank, self.status = bad_rank, status
+        _lib.PeerFailure.__init__(self, _lib.GP_EPEER, "rank %d of the group failed with status %d; no result was exchanged" % (bad_rank, status))
+        self.bad_rank, self.peer_status = bad_rank, status
 
 
 def status_scan(status, rank):

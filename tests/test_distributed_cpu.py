@@ -100,6 +100,7 @@ def _failing_worker(rank, world, port, out):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     sys.path.insert(0, ROOT)
     from gp_algos_amd import dist
+    from gp_algos_amd import _lib
     from gp_algos_amd._lib import GpCoreError
     dist.init("gloo")
     thetas = np.arange(15.0).reshape(5, 3)
@@ -112,8 +113,9 @@ def _failing_worker(rank, world, port, out):
     got = None
     try:
         dist.lml_grad_sharded(evaluate, thetas)
-    except dist.PeerFailure as e:
-        got = ("peer", e.bad_rank, e.status)
+    except _lib.PeerFailure as e:             # ONE exception class for a failed peer, whichever exchange reported it (dist.PeerFailure
+        assert isinstance(e, dist.PeerFailure) and e.status == _lib.GP_EPEER   # is a subclass of the C-ABI's _lib.PeerFailure)
+        got = ("peer", e.bad_rank, e.peer_status)
     except GpCoreError as e:
         got = ("own", rank, e.status)
     # the group is still usable afterwards: nobody is stuck inside a collective, nothing is half-exchanged
