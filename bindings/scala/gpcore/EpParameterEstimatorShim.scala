@@ -47,7 +47,8 @@ object EpParameterEstimator {
   case class CavityDistributionParams(tauParams: DenseVector[Double], niParams: DenseVector[Double])
   case class EpEstimationContext(oldParams: SiteParams, currentParams: SiteParams)
 
-  class AvgBasedStopCriterion(eps: Double) extends stopCriterionFunc {
+  /** `val eps` (the reference keeps it as a plain constructor parameter, :187): the batched device paths need to read it back */
+  class AvgBasedStopCriterion(val eps: Double) extends stopCriterionFunc {
     def apply(context: EpEstimationContext): Boolean =
       abs(avgBetweenSiteParams(context.oldParams, context.currentParams)) < eps
   }

@@ -13,6 +13,12 @@ class MarginalLikelihoodEvaluator(stopCriterion: EpParameterEstimator.stopCriter
   import MarginalLikelihoodEvaluator._
   import Native.{defaultCtx => ctx, dense, rethrowNotPd}
 
+  /** what the batched device paths (HyperParamsOptimization / MeshHyperParamsLogLikelihoodEvaluator shims) need to know: the kernel,
+    * and the eps of the stop criterion when it is the reference's AvgBasedStopCriterion (the only criterion the library evaluates
+    * itself, per problem and sweep, operator precedence as written) */
+  def kernel: KernelFunc = kernelFunc
+  def stopEps: Option[Double] = stopCriterion match { case a: AvgBasedStopCriterion => Some(a.eps); case _ => None }
+
   def logLikelihoodWithKernelMatrixPassed(kernelMatrix: DenseMatrix[Double], targets: DenseVector[Int]): Double =
     new EpParameterEstimator(kernelMatrix, targets, stopCriterion).estimateSiteParams._1.marginalLogLikelihood.get
 

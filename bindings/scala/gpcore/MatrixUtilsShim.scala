@@ -69,6 +69,25 @@ object MatrixUtils {
     new DenseMatrix(n, n, out)
   }
 
+  /** dK/dhp_pos of gp.regression.Co2Prediction.Co2Kernel (Co2Prediction.scala:66-137) over 1-D inputs, on the device: what
+    * buildMatrixWithFunc(X)(co2Kernel.derAfterHyperParam(pos)) builds; `theta` = hp1..hp11 */
+  def buildCo2DerivativeMatrix(theta: DenseVector[Double], data: DenseMatrix[Double], pos: Int): kernelMatrixType = {
+    require(data.cols == 1, "This kernel is applicable only for 1D objects")
+    val n = data.rows; val out = new Array[Double](n * n)
+    Native.dgramCo2(ctx, data(::, 0).toArray, n, theta.toArray, pos, out)
+    new DenseMatrix(n, n, out)
+  }
+
+  /** breeze.linalg.cholesky(A) for the reference's own call sites that hold a ready-made matrix (GpPredictor.scala:120,
+    * EpParameterEstimator.scala:58, UnscentedKalmanFilter.scala:90): lower factor with a zero upper triangle, on the device;
+    * a non-positive pivot throws what Breeze throws. */
+  def choleskyLower(a: DenseMatrix[Double]): DenseMatrix[Double] = {
+    require(a.rows == a.cols)
+    val l = a.copy
+    Native.rethrowNotPd { Native.potrfLower(ctx, l.data, l.offset, l.rows, l.majorStride) }
+    l
+  }
+
   def buildMatrixWithFunc(data: DenseMatrix[Double])(f: (DenseVector[Double], DenseVector[Double], Boolean) => Double): kernelMatrixType = {
     val n = data.rows
     val result = DenseMatrix.zeros[Double](n, n)

@@ -67,6 +67,10 @@ object Native {
   /** one context per JVM unless the caller builds its own; device from -Dgpcore.device (default 0) */
   lazy val defaultCtx: Long = ctxCreate(Integer.getInteger("gpcore.device", 0))
 
+  /** give cached device workspaces back (gp_ctx_trim) / release the default context at JVM shutdown */
+  def trim(): Unit = ctxTrim(defaultCtx)
+  def shutdown(): Unit = ctxDestroy(defaultCtx)
+
   /** -Dgpcore.strict=false selects the intended EP formulas instead of the reference's as-compiled ones (SURVEY.md A19/A22) */
   lazy val strict: Boolean = java.lang.Boolean.parseBoolean(System.getProperty("gpcore.strict", "true"))
 

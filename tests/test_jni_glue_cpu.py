@@ -55,3 +55,39 @@ def test_forwards_named_missing_in_round_2_exist():
     for sym in ("gp_ep_lml_grad_rbf_batched", "gp_small_from_factors", "gp_small_get", "gp_small_size", "gp_gram_co2", "gp_dgram_co2",
                 "gp_cross_gram_co2", "gp_lml_grad_from_gram"):
         assert sym + "(" in src, sym
+
+
+def _shim_sources():
+    d = os.path.join(ROOT, "bindings", "scala", "gpcore")
+    return {f: open(os.path.join(d, f)).read() for f in sorted(os.listdir(d)) if f.endswith(".scala")}
+
+
+def test_every_native_is_called_by_a_shim():
+    """VERDICT r03 missing #2: a forward nobody calls is a device path the JVM cannot reach.  Every `@native def` of Native.scala
+    must be used by one of the Scala shims (Native.scala's own helpers count for the context calls)."""
+    src = _shim_sources()
+    natives = _scala_natives()
+    body = {f: re.sub(r"@native\s+def\s+\w+", "", s) for f, s in src.items()}        # the declarations themselves are not uses
+    unused = [n for n in natives if not any(re.search(r"\bNative\.%s\b|(?<![\w.])%s\(" % (n, n), s) for s in body.values())]
+    assert not unused, "declared @native but called by no shim: %s" % unused
+
+
+def test_l3_caller_shims_exist_and_use_the_batched_entry_points():
+    """The reference's L3 callers (GPOptimizer.scala:47-109, GPUnscentedKalmanFilter.scala:63-147, HyperParamsOptimization.scala:31-55,
+    MeshHyperParamsLogLikelihoodEvaluator.scala:18-40) reach the batched device paths through their shims."""
+    src = _shim_sources()
+    want = {"GPOptimizerShim.scala": ("package gp.optimization", "class GPOptimizer(", "Native.smallFit", "Native.smallAppend", "Native.smallMaximizeUcb", "Native.smallUcb"),
+            "GPUnscentedKalmanFilterShim.scala": ("package dynamicalsystems.filtering", "class GPUnscentedKalmanFilter(", "Native.smallFit", "Native.smallFromFactors", "Native.smallPosterior"),
+            "HyperParamsOptimizationShim.scala": ("package gp.classification", "object HyperParamsOptimization", "class GradientHyperParamsOptimizer(", "Native.epOptimizeRbf"),
+            "MeshHyperParamsLogLikelihoodEvaluatorShim.scala": ("package gp.classification", "class MeshHyperParamsLogLikelihoodEvaluator(", "logLikelihoodOverMesh", "Native.epLmlGradRbfBatched"),
+            "Dist.scala": ("Native.distUniqueId", "Native.distInit", "Native.distLmlGradBatched", "Native.distPredict", "Native.distDestroy")}
+    for f, needles in want.items():
+        assert f in src, f
+        for nd in needles:
+            assert nd in src[f], (f, nd)
+    for f, s in src.items():       # crude syntax hygiene (no JDK / scalac here): balanced delimiters outside strings and comments
+        t = re.sub(r'"""(?:.|\n)*?"""|"(?:\\.|[^"\\])*"', '""', s)
+        t = re.sub(r"/\*(?:.|\n)*?\*/|//[^\n]*", "", t)
+        t = re.sub(r"'(?:\\.|[^'\\])'", "' '", t)
+        for a, b in ("()", "[]", "{}"):
+            assert t.count(a) == t.count(b), "%s: unbalanced %s%s (%d vs %d)" % (f, a, b, t.count(a), t.count(b))
