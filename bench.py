@@ -309,14 +309,20 @@ def run_secondary(args):
             tau, nu = ep.sweep(sweeps)
             progress("c4: %d sweeps done" % sweeps)
         fence()
+        progress("c4: fence after the timed sweeps passed")
         dt = gdist.max_over_ranks(time.perf_counter() - t0, device=coll_dev)
         # the roofline block's HIP events (two per launch of the profiled classes, on four streams) cost this latency-bound workload
-        # ~5 %: they are taken on ONE extra step after the timed ones
-        ctx.profile(prof_mask)
-        ep.sweep(sweeps)
-        fence()
-        ctx.profile(0)
-        progress("c4: profiled sweeps done")
+        # ~5 %: they are taken on ONE extra step after the timed ones.  --no-roofline-events leaves that step out (the roofline block
+        # is then null): a rocprofv3 --pmc pass only needs the kernels to run, and the WRITE_SIZE pass of this workload stopped
+        # in exactly this step (profiles/r04_a_pmc_c4_WRITE_SIZE_probe.log)
+        if not args.no_roofline_events:
+            ctx.profile(prof_mask)
+            for part in range(5):
+                ep.sweep(sweeps // 5)
+                progress("c4: %d profiled sweeps done" % ((part + 1) * (sweeps // 5)))
+            fence()
+            ctx.profile(0)
+            progress("c4: profiled sweeps done")
         names_c4 = dict(names)
         names_c4[L.GP_PROF_SYRK] = ("gemm_nt_f64_kernel<1,*> / gemm_k128_kernel<1> (lower-trapezoid products of the refactorisation that runs under "
                                     "the site loop: K = 512 trailing updates, next covariance -= Vt Vt^T; launched on two side streams, so a "
@@ -588,6 +594,8 @@ def main():
                          "(the launch path of --gpus N, testable on a host without a GPU)")
     ap.add_argument("--cpu-fit-full", action="store_true", help="cpu_baseline: time the oracle's fit at the full n (about a minute)")
     ap.add_argument("--no-c3", action="store_true", help="leave the c3_sharded block out of the c2 line")
+    ap.add_argument("--no-roofline-events", action="store_true",
+                    help="c4: skip the extra step that records HIP events around every launch of the profiled classes (for rocprofv3 --pmc passes)")
     args = ap.parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # no launcher around us: become one.  Nothing above this line imports torch or loads libgpcore.so.

@@ -88,11 +88,6 @@ gp_status read_info(gp_ctx *ctx, int *info) {
     int h = 0;
     GP_HIP(ctx, hipMemcpyAsync(&h, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     GP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (h < 0) {   // chol_wait_flag_kernel gave up (chol_fused): never seen on real hardware queues, reported rather than hung
-        if (info) *info = 0;
-        GP_SET_ERR(ctx, "Cholesky: a device flag of the fused diagonal chain did not arrive within its bound");
-        return GP_EHIP;
-    }
     if (info) *info = h;
     return GP_OK;
 }
@@ -129,112 +124,6 @@ void gemm_sub_single(hipStream_t s, int M, int N, int K, const double *A, int ld
 //       stream, under the next panel's chain of single-workgroup kernels (which need a whole CU's LDS: the mask keeps CUs free).
 // `extra` (0 or GP_NB) rows below the matrix ride along: with y^T in row np this leaves (L^-1 y)^T there.
 // count > 1: a lockstep batch -- problem g lives at A + g*strideA, dinv + g*strideDinv, info + g; every launch covers all of them.
-// Per-step resources of the fused diagonal chain (chol_fused): 2 events per 128-column step + 2 spare, one flag per step
-bool chol_fused_reserve(gp_ctx *ctx, int nblk) {
-    if (ctx->cflags_cap < nblk) {
-        if (ctx->d_cflags) (void)hipFree(ctx->d_cflags);
-        ctx->d_cflags = nullptr, ctx->cflags_cap = 0;
-        if (hipMalloc(&ctx->d_cflags, sizeof(int) * (size_t)nblk) != hipSuccess) { (void)hipGetLastError(); return false; }
-        if (hipMemset(ctx->d_cflags, 0, sizeof(int) * (size_t)nblk) != hipSuccess) return false;
-        ctx->cflags_cap = nblk;
-    }
-    while ((int)ctx->chol_ev.size() < 2 * nblk + 2) {
-        hipEvent_t ev = nullptr;
-        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return false;
-        ctx->chol_ev.push_back(ev);
-    }
-    return true;
-}
-
-// Single factorisation with ONE launch per step on its diagonal chain (potrf_link128_kernel): within an outer panel, step k's kernel
-// first solves its own 128 rows of block column k-1 and applies them to its diagonal block (what the panel solve and the in-panel
-// update did for it: two launches of the old chain), then factors.  The rest of step k-1 -- the panel solve of the rows below
-// block k, the in-panel update of everything but block k's diagonal tile -- runs on a helper stream beside it: the solve as soon as
-// step k-1's diagonal block is factored, the update as soon as step k's kernel has announced its solved rows (device flag, bounded
-// wait); step k+1's kernel waits for that update.  Outer panels as in chol_blocked: K = OUTER update of the next panel's columns on
-// the main stream, of everything to the right on the CU-masked side stream under the next panel's chain.
-//   old chain per step: diagonal block 24.5 us -> panel solve 13.8 -> in-panel update 22.4, three dependent launches
-//   new chain per step: one launch (link ~20 us + factorisation 24.5 us); solve + update of the rest run beside it
-void chol_fused(gp_ctx *ctx, double *A, int np, int lda, double *dinv, int extra, int OUTER, bool lookahead) {
-    hipStream_t s = ctx->stream, sF = ctx->side, sA = ctx->side2;
-    const int rows = np + extra, nblk = np / GP_NB;
-    int *info = ctx->d_info;
-    const int token = ++ctx->chol_epoch;
-    hipEvent_t ev_join = ctx->chol_ev[2 * nblk], ev_start = ctx->chol_ev[2 * nblk + 1];
-    (void)hipEventRecord(ev_start, s);
-    (void)hipStreamWaitEvent(sA, ev_start, 0);      // the helper stream starts behind whatever the main stream holds now
-    bool side_busy = false;
-    for (int K0 = 0; K0 < np; K0 += OUTER) {
-        const int wcols = std::min(OUTER, np - K0), pe = K0 + wcols;
-        for (int k0 = K0; k0 < pe; k0 += GP_NB) {
-            const int b = k0 / GP_NB;
-            const bool first = k0 == K0, last = k0 + GP_NB == pe;
-            double *Akk = A + (size_t)k0 + (size_t)k0 * lda;
-            double *dk = dinv + (size_t)k0 * 16;
-            hipEvent_t ev_fac = ctx->chol_ev[2 * b], ev_side = ctx->chol_ev[2 * b + 1];
-            // the link reads A[blk b, blk b-1 .. b]: entries the helper stream's in-panel update of step b-2 wrote (same panel only:
-            // across a panel boundary they come from the outer update, which is on this stream)
-            if (!first && k0 - 2 * GP_NB >= K0) (void)hipStreamWaitEvent(s, ctx->chol_ev[2 * (b - 2) + 1], 0);
-            gp_prof_begin(ctx, GP_PROF_POTRF_DIAG);
-            if (first) gpk_potrf_diag128(s, Akk, lda, dk, info, k0, gp_batch());
-            else gpk_potrf_link128(s, Akk, lda, dk, info, k0, ctx->d_cflags + b, token);
-            gp_prof_end(ctx, GP_PROF_POTRF_DIAG, (double)GP_NB * GP_NB * GP_NB / 3.0 + (first ? 0.0 : 3.0 * GP_NB * GP_NB * GP_NB));
-            (void)hipEventRecord(ev_fac, s);
-            if (!first) {
-                // helper stream: in-panel update of step b-1 -- rows from block b on, columns block b .. panel end, minus block b's own
-                // diagonal block (this step's kernel owns it) -- once this step's kernel has announced its rows of block column b-1
-                const int M = rows - k0, wc = pe - k0;
-                const double *P = A + (size_t)k0 + (size_t)(k0 - GP_NB) * lda;
-                gpk_chol_wait_flag(sA, ctx->d_cflags + b, token, info);
-                gp_prof_begin(ctx, GP_PROF_PANEL_UPD, sA);
-                gpk_gemm_k128_sub(sA, M, wc, P, lda, P, lda, A + (size_t)k0 + (size_t)k0 * lda, lda, 1, GP_NB, GP_NB);
-                gp_prof_end(ctx, GP_PROF_PANEL_UPD, trapezoid_flops(M, wc, GP_NB) - 2.0 * GP_NB * GP_NB * GP_NB, sA);
-                (void)hipEventRecord(ctx->chol_ev[2 * (b - 1) + 1], sA);
-            }
-            // helper stream: panel solve of step b for the rows below block b+1 (block b+1's own rows are its kernel's link; the last
-            // step of a panel has no successor with a link, so it solves everything below)
-            const int r = rows - (k0 + GP_NB), skip = last ? 0 : GP_NB;
-            if (r - skip > 0) {
-                (void)hipStreamWaitEvent(sA, ev_fac, 0);
-                gp_prof_begin(ctx, GP_PROF_TRSM, sA);
-                gpk_trsm_panel128(sA, Akk + GP_NB + skip, r - skip, lda, Akk, lda, dk, nullptr, nullptr, nullptr, gp_batch());
-                gp_prof_end(ctx, GP_PROF_TRSM, (double)(r - skip) * GP_NB * GP_NB, sA);
-            }
-            (void)ev_side;
-        }
-        const int c1 = pe, R = np - c1;
-        if (R <= 0) break;
-        // the panel is complete when the helper stream has finished its last solve (its updates come before that in stream order)
-        (void)hipEventRecord(ev_join, sA);
-        (void)hipStreamWaitEvent(s, ev_join, 0);
-        if (side_busy) { (void)hipStreamWaitEvent(s, ctx->ev_b, 0); side_busy = false; }
-        const double *P = A + (size_t)c1 + (size_t)K0 * lda;
-        const int nnext = lookahead ? std::min(OUTER, R) : R;
-        if (R > nnext) {
-            (void)hipEventRecord(ctx->ev_a, s);
-            (void)hipStreamWaitEvent(sF, ctx->ev_a, 0);
-            const int c2 = c1 + nnext;
-            const double *P2 = A + (size_t)c2 + (size_t)K0 * lda;
-            gp_prof_begin(ctx, GP_PROF_SYRK, sF);
-            gpk_gemm_nt(sF, rows - c2, np - c2, wcols, -1.0, P2, lda, P2, lda, 1.0, A + (size_t)c2 + (size_t)c2 * lda, lda, 1);
-            gp_prof_end(ctx, GP_PROF_SYRK, trapezoid_flops(rows - c2, np - c2, wcols), sF);
-            (void)hipEventRecord(ctx->ev_b, sF);
-            side_busy = true;
-        }
-        gp_prof_begin(ctx, GP_PROF_SYRK);
-        const double tiles128 = trapezoid_flops(rows - c1, nnext, wcols) / (2.0 * GP_NB * GP_NB * wcols);
-        if (tiles128 < small_update_tiles() && small_panel_update())
-            gpk_gemm_k128_sub(s, rows - c1, nnext, P, lda, P, lda, A + (size_t)c1 + (size_t)c1 * lda, lda, 1, wcols);
-        else
-            gpk_gemm_nt(s, rows - c1, nnext, wcols, -1.0, P, lda, P, lda, 1.0, A + (size_t)c1 + (size_t)c1 * lda, lda, 1);
-        gp_prof_end(ctx, GP_PROF_SYRK, trapezoid_flops(rows - c1, nnext, wcols));
-    }
-    // everything the helper streams still hold is ordered before whatever the main stream does next
-    (void)hipEventRecord(ev_join, sA);
-    (void)hipStreamWaitEvent(s, ev_join, 0);
-    if (side_busy) (void)hipStreamWaitEvent(s, ctx->ev_b, 0);
-}
-
 void chol_blocked(gp_ctx *ctx, double *A, int np, int lda, double *dinv, int extra, int count = 1, size_t strideA = 0, size_t strideDinv = 0,
                   int *info = nullptr) {
     hipStream_t s = ctx->stream, s2 = ctx->side;
@@ -255,19 +144,11 @@ void chol_blocked(gp_ctx *ctx, double *A, int np, int lda, double *dinv, int ext
     // outer panel width: 512 (K = 512 trailing updates); 1024 measured 3 % faster at n = 32768 (205 -> 198.5 ms), equal at 8192
     const int outer_env = gp_env_blocks("GPCORE_OUTER");
     const int OUTER = outer_env ? outer_env : (np > 16384 ? 2 * GP_OUTER : GP_OUTER);
-    {   // GPCORE_CHOL_FUSED = 1: one launch per step on the diagonal chain (chol_fused).  OFF by default: measured slower at every size
-        // (refit ms three-launch chain / fused: n = 4096 1.99 / 2.23, n = 8192 6.01 / 6.35, n = 12288 14.41 / 15.04, n = 16384 30.2 /
-        // 30.6; profiles/r03_q_fit_fused.log).  The link's 128-row solve and 36-tile update are 4.7 MFLOP that ONE CU's matrix pipes
-        // take ~20 us over (EP's chain kernel pays the same, profiles/r03_i_block2_stamps.txt) -- as long as the panel solve and the
-        // in-panel update they replace take on the whole chip (13.8 + 22.4 us), and the helper stream's update, which can only
-        // start at the flag, now sits between two steps.  Read per call so that a test can run both forms in one process.
-        const char *fe = getenv("GPCORE_CHOL_FUSED");
-        const bool want = fe && atoi(fe) != 0;
-        if (want && count == 1 && info == ctx->d_info && np >= 2 * GP_NB && ctx->side2 && chol_fused_reserve(ctx, np / GP_NB)) {
-            chol_fused(ctx, A, np, lda, dinv, extra, OUTER, lookahead);
-            return;
-        }
-    }
+    // (Round 4 tried the chain on the outer panel's OWN rows only, with the rows under the panel -- panel solve and their share of the
+    // in-panel update -- on a second stream gated by one event per step: bit-identical, and slower at every size (n = 8192 refit 6.86
+    // against 5.93 ms, profiles/r04_b_chol_split_fit.log).  Those launches are throughput work the step has to do anyway; moved off
+    // the chain they queue behind the far update's workgroups like every other launch, and each step pays two more launches and a
+    // cross-stream event.  Removed again; what the chip idles through is the 24.5 us of the single-workgroup diagonal block.)
     for (int K0 = 0; K0 < np; K0 += OUTER) {
         const int wcols = std::min(OUTER, np - K0);
         for (int k0 = K0; k0 < K0 + wcols; k0 += GP_NB) {
@@ -304,6 +185,9 @@ void chol_blocked(gp_ctx *ctx, double *A, int np, int lda, double *dinv, int ext
             const int c2 = c1 + nnext;
             const double *P2 = A + (size_t)c2 + (size_t)K0 * lda;
             gp_prof_begin(ctx, GP_PROF_SYRK, s2);
+            static const bool far_small = [] { const char *e = getenv("GPCORE_FAR_SMALL"); return e && atoi(e) != 0; }();   // lab switch (round 4)
+            if (far_small) gpk_gemm_k128_sub(s2, rows - c2, np - c2, P2, lda, P2, lda, A + (size_t)c2 + (size_t)c2 * lda, lda, 1, wcols);
+            else
             gpk_gemm_nt(s2, rows - c2, np - c2, wcols, -1.0, P2, lda, P2, lda, 1.0, A + (size_t)c2 + (size_t)c2 * lda, lda, 1);
             gp_prof_end(ctx, GP_PROF_SYRK, trapezoid_flops(rows - c2, np - c2, wcols), s2);
             (void)hipEventRecord(ctx->ev_b, s2);
@@ -494,6 +378,7 @@ gp_status model_alloc(gp_ctx *ctx, int n, int d, bool has_x, gp_model **out) {
     const size_t np = m->np;
     hipError_t e = hipSuccess;
     if (has_x) e = hipMalloc(&m->dX, sizeof(double) * (size_t)n * d);
+    if (has_x && e == hipSuccess) e = hipMalloc(&m->dcen, sizeof(double) * 64);
     if (e == hipSuccess) e = hipMalloc(&m->dy, sizeof(double) * np);
     if (e == hipSuccess) e = hipMalloc(&m->dL, sizeof(double) * (np + GP_NB) * np);
     if (e == hipSuccess) e = hipMalloc(&m->dalpha, sizeof(double) * np);
@@ -635,10 +520,10 @@ gp_status gpi_ctx_ep_streams(gp_ctx *ctx) {
     if (const char *rc = getenv("GPCORE_RESERVED_CUS_EP")) reserved_ep = atoi(rc);
     // side2 carries the factorisation chain: its workgroups are short-lived (quarter-size tiles) but its single-workgroup
     // diagonal kernel needs a whole CU's LDS, which it only finds quickly on the CUs the masked streams leave alone -- so side2
-    // itself is NOT masked.  (GPCORE_EP_CHAIN_MASK=k keeps k CUs free of side2 as well; measured with the 25 us diagonal kernel,
-    // k = 0 / 8 / 16 / 24 / 32: 163.5 / 162.7 / 163.2 / 162.3 / 164.3 sweeps/s at n = 4096 -- no effect, so the slow-down of the
-    // site loop's small kernels while the other streams' GEMMs run is not a matter of finding a free CU.)
-    const int chain_reserved = [] { const char *m = getenv("GPCORE_EP_CHAIN_MASK"); return m ? atoi(m) : 0; }();
+    // itself is NOT masked.  (Keeping k CUs free of side2 as well was measured with the 25 us diagonal kernel, k = 0 / 8 / 16 / 24 / 32:
+    // 163.5 / 162.7 / 163.2 / 162.3 / 164.3 sweeps/s at n = 4096 -- no effect, so the slow-down of the site loop's small kernels
+    // while the other streams' GEMMs run is not a matter of finding a free CU; the switch is gone.)
+    const int chain_reserved = 0;
     for (hipStream_t *sp : {&ctx->side2, &ctx->side3}) {
         if (e != hipSuccess) break;
         em = hipErrorInvalidValue;
@@ -697,7 +582,16 @@ gp_status gp_ctx_create(int device, void *stream, gp_ctx **out) {
     }
     if (e == hipSuccess) {
         if (stream) { ctx->stream = static_cast<hipStream_t>(stream); ctx->own_stream = false; }
-        else { e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking); ctx->own_stream = true; }
+        else {
+            // lab switch (round 4): the caller-facing stream at the highest priority the device offers, so that the chain's kernels go
+            // ahead of the helper streams' workgroups whenever a CU slot frees
+            const char *pe = getenv("GPCORE_MAIN_PRIORITY");
+            int lo = 0, hi = 0;
+            if (pe && atoi(pe) != 0 && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess)
+                e = hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, hi);
+            else e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+            ctx->own_stream = true;
+        }
     }
     if (e == hipSuccess) {
         // Side stream for the far trailing update of the Cholesky.  It is CU-masked to leave a few CUs free of its
@@ -728,8 +622,8 @@ gp_status gp_ctx_create(int device, void *stream, gp_ctx **out) {
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_b, hipEventDisableTiming);
     if (const char *la = getenv("GPCORE_LOOKAHEAD")) ctx->lookahead = atoi(la) != 0 ? 1 : 0;
     if (e == hipSuccess) e = hipMalloc(&ctx->d_scalars, sizeof(double) * 256);
-    if (e == hipSuccess) e = hipMalloc(&ctx->d_info, sizeof(int) * 8);
-    if (e == hipSuccess) e = hipMemset(ctx->d_info, 0, sizeof(int) * 8);
+    if (e == hipSuccess) e = hipMalloc(&ctx->d_info, sizeof(int) * 8 + sizeof(double) * 64);      // 8 status ints, then gp_gram_center's 64 doubles
+    if (e == hipSuccess) e = hipMemset(ctx->d_info, 0, sizeof(int) * 8 + sizeof(double) * 64);
     if (e == hipSuccess && (gpk_init_diag_kernels() != 0 || gpk_init_gemm_kernels() != 0)) e = hipErrorInvalidValue;
     if (e != hipSuccess) { delete ctx; return GP_EHIP; }
     *out = ctx;
@@ -749,9 +643,6 @@ void gp_ctx_destroy(gp_ctx *ctx) {
     for (int i = 0; i < WS_COUNT; ++i) if (x->ws[i].p) (void)hipFree(x->ws[i].p);
     if (ctx->d_scalars) (void)hipFree(ctx->d_scalars);
     if (ctx->d_info) (void)hipFree(ctx->d_info);
-    if (ctx->d_cflags) (void)hipFree(ctx->d_cflags);
-    for (hipEvent_t e : ctx->chol_ev) (void)hipEventDestroy(e);
-    ctx->chol_ev.clear();
     if (ctx->ev_a) (void)hipEventDestroy(ctx->ev_a);
     if (ctx->ev_b) (void)hipEventDestroy(ctx->ev_b);
     if (ctx->side) (void)hipStreamDestroy(ctx->side);
@@ -872,7 +763,8 @@ gp_status gp_gram_rbf_dev(gp_ctx *ctx, const double *dX, int n, int d, int ldx, 
     GP_REQUIRE(ctx, n >= 0 && d >= 1 && d <= 64 && ldx >= n && ldk >= n, "bad dimensions (1 <= d <= 64)");
     if (n == 0) return GP_OK;
     gp_prof_begin(ctx, GP_PROF_GRAM);
-    gpk_gram_sym(ctx->stream, dX, n, d, ldx, theta, dK, ldk, uplo == GP_FULL, 0.0, gp_gram_flag(ctx));
+    gpk_centroid(ctx->stream, dX, n, d, ldx, gp_gram_center(ctx));
+    gpk_gram_sym(ctx->stream, dX, n, d, ldx, theta, dK, ldk, uplo == GP_FULL, 0.0, gp_gram_flag(ctx), gp_gram_center(ctx));
     gp_prof_end(ctx, GP_PROF_GRAM, uplo == GP_FULL ? 8.0 * n * (double)n + 8.0 * n * d : 8.0 * n * (n + 1.0) / 2.0 + 8.0 * n * d);
     return GP_OK;
 }
@@ -921,7 +813,8 @@ gp_status gp_cross_gram_rbf(gp_ctx *ctx, const double *Xs, int m, int ldxs, cons
     GP_TRY(ws_get(ctx, WS_B, sizeof(double) * (size_t)m * n, &dK));
     GP_TRY(upload_2d(ctx, dXs, m, Xs, ldxs, m, d));
     GP_TRY(upload_2d(ctx, dX, n, X, ldx, n, d));
-    gpk_gram_cross(ctx->stream, dXs, m, m, dX, n, n, d, theta, dK, m, gp_gram_flag(ctx));
+    gpk_centroid(ctx->stream, dX, n, d, n, gp_gram_center(ctx));
+    gpk_gram_cross(ctx->stream, dXs, m, m, dX, n, n, d, theta, dK, m, gp_gram_flag(ctx), gp_gram_center(ctx));
     return download_2d(ctx, Ks, ldks, dK, m, m, n);
 }
 
@@ -976,7 +869,7 @@ gp_status gp_model_refit_dev(gp_model *m, const double *theta, double sigma_nois
     m->sigma_noise = sigma_noise;
     gp_prof_begin(ctx, GP_PROF_GRAM);
     if (m->kind == 1) gpk_co2_gram(ctx->stream, m->dX, m->n, m->dX, m->n, theta, 0, m->dL, m->ldl, 1, 0, std::isnan(sigma_noise) ? 0.0 : sigma_noise);
-    else gpk_gram_sym(ctx->stream, m->dX, m->n, m->d, m->n, theta, m->dL, m->ldl, 0, std::isnan(sigma_noise) ? 0.0 : sigma_noise, gp_gram_flag(ctx));
+    else gpk_gram_sym(ctx->stream, m->dX, m->n, m->d, m->n, theta, m->dL, m->ldl, 0, std::isnan(sigma_noise) ? 0.0 : sigma_noise, gp_gram_flag(ctx), m->dcen);
     gp_prof_end(ctx, GP_PROF_GRAM, 8.0 * m->n * (m->n + 1.0) / 2.0 + 8.0 * m->n * m->d);
     model_factor(m);
     GP_LAUNCH_CHECK(ctx);
@@ -1003,6 +896,7 @@ gp_status gp_fit_rbf_dev(gp_ctx *ctx, const double *dX, int n, int d, int ldx, c
     gp_model *m = nullptr;
     GP_TRY(model_alloc(ctx, n, d, true, &m));
     gpk_copy_2d(ctx->stream, m->dX, n, dX, ldx, n, d);
+    gpk_centroid(ctx->stream, m->dX, n, d, n, m->dcen);
     hipError_t e = hipMemcpyAsync(m->dy, dy, sizeof(double) * n, hipMemcpyDeviceToDevice, ctx->stream);
     if (e != hipSuccess) { gp_model_destroy(m); GP_SET_ERR(ctx, "copy y: %s", hipGetErrorString(e)); return GP_EHIP; }
     gp_status st = gp_model_refit_dev(m, theta, sigma_noise);
@@ -1022,6 +916,7 @@ gp_status gp_fit_rbf(gp_ctx *ctx, const double *X, int n, int d, int ldx, const 
     gp_model *m = nullptr;
     GP_TRY(model_alloc(ctx, n, d, true, &m));
     gp_status st = upload_2d(ctx, m->dX, n, X, ldx, n, d);
+    if (st == GP_OK) gpk_centroid(ctx->stream, m->dX, n, d, n, m->dcen);
     if (st == GP_OK) st = upload_2d(ctx, m->dy, n, y, n, n, 1);
     if (st == GP_OK) st = gp_model_refit_dev(m, theta, sigma_noise);
     if (st == GP_OK) st = gp_model_status(m, info);
@@ -1121,6 +1016,7 @@ void gp_model_destroy(gp_model *m) {
     if (!m) return;
     if (m->ctx) { (void)hipSetDevice(m->ctx->device); (void)hipStreamSynchronize(m->ctx->stream); }
     if (m->dX) (void)hipFree(m->dX);
+    if (m->dcen) (void)hipFree(m->dcen);
     if (m->dy) (void)hipFree(m->dy);
     if (m->dL) (void)hipFree(m->dL);
     if (m->dalpha) (void)hipFree(m->dalpha);
@@ -1147,7 +1043,7 @@ static gp_status predict_core(gp_model *mdl, const double *dXs, int m, int ldxs,
     }
     gp_prof_begin(ctx, GP_PROF_GRAM);
     if (mdl->kind == 1) gpk_co2_gram(s, dXs, m, mdl->dX, n, mdl->theta.data(), 0, Vt, mp, 0, 1, 0.0);
-    else gpk_gram_cross(s, dXs, m, ldxs, mdl->dX, n, n, mdl->d, mdl->theta.data(), Vt, mp, gp_gram_flag(ctx));
+    else gpk_gram_cross(s, dXs, m, ldxs, mdl->dX, n, n, mdl->d, mdl->theta.data(), Vt, mp, gp_gram_flag(ctx), mdl->dcen);
     gp_prof_end(ctx, GP_PROF_GRAM, 8.0 * m * (double)n + 8.0 * (m + n) * mdl->d);
     // sumsq and the mean accumulate inside the row-panel solves: var = kss - |v|^2, mean = v . (L^-1 y)  (= K* alpha)
     double *dots = partial;
@@ -1323,7 +1219,8 @@ extern "C" gp_status gp_posterior_from_factor(gp_ctx *ctx, const double *X, int 
     GP_TRY(upload_2d(ctx, dX, n, X, ldx, n, d));
     GP_HIP(ctx, hipMemsetAsync(Vt, 0, sizeof(double) * (size_t)mp * np, s));
     gp_prof_begin(ctx, GP_PROF_GRAM);
-    gpk_gram_cross(s, dXs, m, m, dX, n, n, d, theta, Vt, mp, gp_gram_flag(ctx));
+    gpk_centroid(s, dX, n, d, n, gp_gram_center(ctx));
+    gpk_gram_cross(s, dXs, m, m, dX, n, n, d, theta, Vt, mp, gp_gram_flag(ctx), gp_gram_center(ctx));
     gp_prof_end(ctx, GP_PROF_GRAM, 8.0 * m * (double)n + 8.0 * (m + n) * d);
     GP_TRY(posterior_rows(ctx, Vt, m, mp, f, dout, dout + mp));
     GP_TRY(download_2d(ctx, mean, m, dout, m, m, 1));
@@ -1534,10 +1431,11 @@ gp_status lml_worker_eval(lml_worker &w, const double *thetas, int g, int nparam
     const int np = w.np, n = w.n, d = w.d, P = d + 2, ldl = w.ldl;
     const double extra = std::isnan(sigma_noise) ? 0.0 : sigma_noise;
     GP_HIP(ctx, hipMemsetAsync(w.info, 0, sizeof(int) * g, s));
+    gpk_centroid(s, w.dX, n, d, n, gp_gram_center(ctx));      // one centre for all settings of the group (it does not depend on theta)
     for (int j = 0; j < g; ++j) {
         double *Lj = w.L + j * w.sL;
         gp_prof_begin(ctx, GP_PROF_GRAM);
-        gpk_gram_sym(s, w.dX, n, d, n, thetas + (size_t)j * P, Lj, ldl, 0, extra, gp_gram_flag(ctx));
+        gpk_gram_sym(s, w.dX, n, d, n, thetas + (size_t)j * P, Lj, ldl, 0, extra, gp_gram_flag(ctx), gp_gram_center(ctx));
         gp_prof_end(ctx, GP_PROF_GRAM, 8.0 * n * (n + 1.0) / 2.0 + 8.0 * n * d);
         gpk_pad_identity(s, Lj, n, np, ldl);
         gpk_copy_strided(s, Lj + np, (size_t)ldl, w.dy, 1, np);       // y^T rides through the factorisation in row np

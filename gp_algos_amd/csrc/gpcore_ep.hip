@@ -71,7 +71,7 @@ namespace {
 
 // 1/x to within an ulp or two: v_rcp_f64 + two Newton steps (the body of the IEEE division sequence without its scaling
 // and fix-up instructions; operands here are O(1) variances and precisions, never denormal).  Only used on the serial
-// per-site chain of ep_block_kernel, where every dependent instruction is paid 128 times per block.
+// per-site chain of the block kernels, where every dependent instruction is paid 128 times per block.
 __device__ __forceinline__ double rcp_nr(double x) {
     double r = __builtin_amdgcn_rcp(x);
     double e = fma(-x, r, 1.0);
@@ -105,13 +105,11 @@ __device__ __forceinline__ void ep_chunk_tile(double *A, const double *cs, int L
     for (int rr = 0; rr < 4; ++rr) A[(ri + fr) + (rj + fg + 4 * rr) * LS] = acc[rr];
 }
 
-#ifdef EP_STAMPS   // lab instrumentation (tools/ep_block_stamps.py): cycle stamps of one block's site iterations; never defined in the library build
+#ifdef EP_STAMPS   // lab instrumentation (tools/ep_block2_stamps.py); never defined in the library build
 __device__ unsigned long long ep_stamps[4 * GP_NB];
 // phase stamps of ep_block2_kernel (tools/ep_block2_stamps.py): slot 2k = s_memrealtime (100 MHz), 2k + 1 = s_memtime (shader clock)
 #define EP2_STAMP(k) do { if (i0 == 5 * GP_NB && tid == 0 && blockIdx.x == 0) { ep_stamps[2 * (k)] = __builtin_amdgcn_s_memrealtime(); ep_stamps[2 * (k) + 1] = __builtin_amdgcn_s_memtime(); } } while (0)
-#define EP_STAMP(slot) do { if (i0 == 5 * GP_NB) ep_stamps[(slot)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
-#define EP_STAMP(slot) do { } while (0)
 #define EP2_STAMP(k) do { } while (0)
 #endif
 
@@ -122,254 +120,10 @@ __device__ unsigned long long ep_stamps[4 * GP_NB];
 // so the 128 x 128 diagonal block of Sigma0, the block of S and mu live in LDS for the whole block.  Outputs: the new
 // site/cavity parameters, c, -coef, and Lmat = I + strict_lower(S_blk diag(c)) -- the unit-lower factor with which the
 // full-height columns follow afterwards from ONE row-panel solve,  S = Sigma0[:, blk] Lmat^-T  (trsm_panel128).
-constexpr int EP_BLOCK_WAVES = 8;   // waves 0,1: one block row per thread; wave 2: the site chain; wave 3: the site outputs; all: chunk-boundary tiles
-__global__ __launch_bounds__(64 * EP_BLOCK_WAVES) void ep_block_kernel(int n, int np, int i0, int bsz, const double *__restrict__ Sig0,
-                                                       const double *__restrict__ mu, const int *__restrict__ y,
-                                                       double *__restrict__ tau, double *__restrict__ nu,
-                                                       double *__restrict__ cav_tau, double *__restrict__ cav_nu,
-                                                       double *__restrict__ cvec, double *__restrict__ ncoef,
-                                                       double *__restrict__ Lmat, double *__restrict__ Ldinv) {
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    constexpr int LS = GP_NB + 1;
-    double *A = sm;                  // column c: Sigma0[blk, i0+c] until site c is processed, afterwards s_c[blk]
-    double *Sb = sm;                 //   (the delayed column replaces the Sigma0 column it was built from)
-    double *cs = sm + GP_NB * LS;    // c
-    double *mb = cs + GP_NB;         // mu restricted to the block
-    double *sc = mb + GP_NB;         // scalars: [0] coef of the current site
-    double *tb = sc + 8;             // the block's site parameters and labels, staged once: a global load per site would put
-    double *nb = tb + GP_NB;         //   an L2 round trip on the serial chain of every one of the 128 site updates
-    double *yb = nb + GP_NB;
-    const int tid = threadIdx.x, r = tid;          // waves 0,1: one block row per thread; wave 2: the site arithmetic
-    const bool rowthread = tid < GP_NB;
-    if (rowthread) {
-#pragma unroll
-        for (int c0 = 0; c0 < GP_NB; c0 += 16) {   // 16 loads in flight per thread (a load/wait/store loop would cost ~100 us)
-            double v[16];
-#pragma unroll
-            for (int c = 0; c < 16; ++c) v[c] = Sig0[(i0 + r) + (size_t)(i0 + c0 + c) * np];
-#pragma unroll
-            for (int c = 0; c < 16; ++c) A[r + (c0 + c) * LS] = v[c];
-        }
-        mb[r] = (i0 + r < n) ? mu[i0 + r] : 0.0;
-        cs[r] = 0.0;
-        const bool live = r < bsz;
-        tb[r] = live ? tau[i0 + r] : 0.0;
-        nb[r] = live ? nu[i0 + r] : 0.0;
-        yb[r] = live ? (double)y[i0 + r] : 0.0;
-    }
-    __syncthreads();
-    // Only entries on or below the diagonal of the block are ever used (s_t[r] matters for r >= t: the mean of the sites still
-    // to come, the unit-lower factor Lmat, and the later columns' own lower parts), and only the lower triangle of Sigma0 is
-    // kept current during a sweep (see gp_ep_sweep); the strict upper triangle of A is dead storage.
-    //
-    // Sites are processed in chunks of 16.  Within a chunk the pipeline is as before: while ONE lane of wave 2 runs the scalar
-    // site update t (the serial chain: erf, exp, reciprocals), waves 0-1 build the terms of s_{t+1} that come from the chunk's
-    // earlier sites (q < t, at most 14 of them); after the barrier they add the q = t term, update mu, and publish column
-    // t+1.  At a chunk boundary the 16 finished columns are applied to ALL later columns at once on the matrix cores
-    //   A[I-tile, J-tile] -= (S[I-tile, chunk] diag(c)) S[J-tile, chunk]^T     for chunk < J <= I
-    // so a site never walks over more than one chunk of history (the former O(t) loop over all earlier sites was the
-    // longest thing in an iteration: 128^2/2 dependent LDS round trips per block).
-    const int lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
-    const int jtiles = (bsz + 15) >> 4;
-    double *cf = sc + 8 + 3 * GP_NB;   // coef of every processed site (rows read it one iteration later)
-    double *pub = cf + GP_NB;          // [2][3]: what the scalar lane needs to start a site: P, B, M (see below), by site parity
-    double *ob = pub + 6;              // [2][5]: what the outputs of a site are made of (1/sii, tau_old, sg, mi, cavity nu), by site parity
-    double *ctb = ob + 10;             // cavity tau and nu of every processed site.  NOTHING is stored to global memory inside the site
-    double *cnb = ctb + GP_NB;         //   loop: a barrier waits for the wave's outstanding stores, i.e. every site would pay an
-                                       //   L2 round trip; the new site parameters replace the staged old ones in tb / nb
-    // One barrier per site.  The scalar lane of wave 2 runs the serial chain of site t (erf, exp, reciprocals) while the row
-    // threads, one site BEHIND it, (i) finish column t with site t-1's result and update the mean, (ii) build the part of
-    // column t+1 that does not depend on site t (q < t, at most 14 terms of the current 16-site chunk) and (iii) row thread
-    // t+1 publishes P = that partial diagonal entry, B = S[t+1, t] and M = mu_{t+1} so far; after the barrier the scalar lane
-    // gets its inputs as  s_ii = P - c_t B^2,  mu_i = M + B coef_t  from its own registers and goes straight into the next
-    // chain.  At a chunk boundary the 16 finished columns are applied to all later columns on the matrix cores.
-    if (tid == 0) { pub[0] = A[0]; pub[1] = 0.0; pub[2] = mb[0]; }
-    __syncthreads();
-    double part = 0.0, c_prev = 0.0, coef_prev = 0.0;
-    double4_t dacc = {0.0, 0.0, 0.0, 0.0};   // waves 4-7: the deferred tile in flight
-    int dcs0 = -1, dJ0 = 8;   // chunk whose update of the later tile columns is still being applied (waves 4-7), first of those columns
-    for (int t = 0; t < bsz; ++t) {
-        const int cs0 = t & ~15;
-        const bool first = (t & 15) == 0;                    // first site of a chunk: its column has no pending term
-        const bool boundary = ((t + 1) & 15) == 0;           // site t closes its chunk
-        const bool build_next = (t + 1 < bsz) && !boundary;  // row threads prepare column t+1 in this iteration
-        if (!rowthread) {
-            if (tid == GP_NB) {
-                EP_STAMP(4 * t + 0);
-                const double *pb = pub + 3 * (t & 1);
-                const double Bv = pb[1];
-                const double sii = fma(-c_prev * Bv, Bv, pb[0]);
-                const double mui = fma(Bv, coef_prev, pb[2]);
-                const double to = tb[t], no = nb[t], yi = yb[t];
-                // The serial chain carries the tilted moments only.  With sigma^2 = sii, the new marginal variance sg and mean mi:
-                //   c = 1/(1/dtau + sii) = (sii - sg)/sii^2,   coef = dnu - c (mui + dnu sii) = (mi - mui)/sii
-                // (substitute dtau = 1/sg - 1/sii, dnu = mi/sg - mui/sii): no reciprocal of sg, of dtau or of 1 + dtau sii on
-                // the chain, and the cavity variance 1/(1/sii - to) = sii/(1 - to sii) is ONE reciprocal deep instead of two.
-                const double rs = rcp_nr(sii);                              // 1/sii, beside the cavity variance
-                const double cvr = sii * rcp_nr(fma(-to, sii, 1.0));        // cavity variance
-                const double nc = fma(mui, rs, -no);                        // cavity nu   :46
-                const double cm = nc * cvr;                                 // cavity mean
-                const double rt = rsqrt(1.0 + cvr);                         // 1/sqrt(1 + sigma^2)
-                const double z = (yi * cm) * rt;
-                const double Phi = 0.5 * (1.0 + erf(z * 0.70710678118654752440));
-                const double ratio = dnorm_d(z) * rcp_nr(Phi);              // phi(z)/Phi(z)
-                const double mi_hat = cm + (yi * cvr) * (ratio * rt);
-                const double sg_hat = cvr - (cvr * cvr) * (ratio * (z + ratio)) * (rt * rt);
-                const double c = (sii - sg_hat) * (rs * rs);                // :53
-                const double coef = (mi_hat - mui) * rs;
-                cs[t] = c;
-                cf[t] = coef;
-                c_prev = c, coef_prev = coef;
-                double *o = ob + 5 * (t & 1);
-                o[0] = rs, o[1] = to, o[2] = sg_hat, o[3] = mi_hat, o[4] = nc;
-                EP_STAMP(4 * t + 1);
-            } else if (wave >= 4) {
-                // deferred tiles of the chunk closed at the last boundary, HALF a tile per site iteration (a whole one takes longer
-                // than the site chain and would hold up the barrier): tile k = 4 (pair of sites within the chunk) + (wave - 4) of the
-                // enumeration J = dJ0 .. jtiles-1, I = J .. 7; first half = accumulator + k-steps 0,1, second half = k-steps 2,3 + store
-                if (dcs0 >= 0) {
-                    const int it = t - (dcs0 + 16);
-                    int k = 4 * (it >> 1) + (wave - 4), I = -1, J = dJ0;
-                    for (; J < jtiles; ++J) {
-                        if (k < 8 - J) { I = J + k; break; }
-                        k -= 8 - J;
-                    }
-                    if (I >= 0) {
-                        const int ri = 16 * I, rj = 16 * J, ks0 = 2 * (it & 1);
-                        if (ks0 == 0) {
-#pragma unroll
-                            for (int rr = 0; rr < 4; ++rr) dacc[rr] = A[(ri + fr) + (rj + fg + 4 * rr) * LS];
-                        }
-#pragma unroll
-                        for (int ks = 0; ks < 2; ++ks) {
-                            const int qq = dcs0 + 4 * (ks0 + ks) + fg;
-                            const double aop = -(cs[qq] * A[(rj + fr) + qq * LS]);
-                            const double bop = A[(ri + fr) + qq * LS];
-                            dacc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, dacc, 0, 0, 0);
-                        }
-                        if (ks0 == 2) {
-#pragma unroll
-                            for (int rr = 0; rr < 4; ++rr) A[(ri + fr) + (rj + fg + 4 * rr) * LS] = dacc[rr];
-                        }
-                    }
-                }
-            } else if (tid == GP_NB + 64 && t > 0) {
-                // wave 3: the outputs of the PREVIOUS site (:45-51 as written).  Nothing in the recurrence waits for them, so they
-                // are computed beside the chain of the current site, from what the chain left in LDS before the last barrier.
-                const double *o = ob + 5 * ((t - 1) & 1);
-                const double tc = o[0] - o[1];                              // cavity tau  :45
-                const double isg = rcp_nr(o[2]);
-                const double dtau = isg - tc - o[1];                        // :49
-                tb[t - 1] = o[1] + dtau;                                    // :50
-                nb[t - 1] = o[3] * isg - o[4];                              // :51
-                ctb[t - 1] = tc;
-                cnb[t - 1] = o[4];
-            }
-        } else {
-            if (!first && r >= t) {     // site t-1's result: mean, and column t becomes final
-                const double st = Sb[r + (t - 1) * LS];
-                mb[r] = fma(st, cf[t - 1], mb[r]);
-                const double wt = cs[t - 1] * Sb[t + (t - 1) * LS];
-                Sb[r + t * LS] = fma(-wt, st, part);
-            }
-            if (build_next && r > t) {
-                double p0 = A[r + (t + 1) * LS], p1 = 0.0, p2 = 0.0, p3 = 0.0;
-                int q = cs0;
-                for (; q + 4 <= t; q += 4) {
-                    double cq[4], sq[4], sr[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        cq[u] = cs[q + u];
-                        sq[u] = Sb[(t + 1) + (q + u) * LS];
-                        sr[u] = Sb[r + (q + u) * LS];
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    p0 = fma(-(cq[0] * sq[0]), sr[0], p0);
-                    p1 = fma(-(cq[1] * sq[1]), sr[1], p1);
-                    p2 = fma(-(cq[2] * sq[2]), sr[2], p2);
-                    p3 = fma(-(cq[3] * sq[3]), sr[3], p3);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                for (; q < t; ++q) p0 = fma(-(cs[q] * Sb[(t + 1) + q * LS]), Sb[r + q * LS], p0);
-                part = (p0 + p1) + (p2 + p3);
-                if (r == t + 1) {
-                    double *pb = pub + 3 * ((t + 1) & 1);
-                    pb[0] = part;
-                    pb[1] = Sb[(t + 1) + t * LS];     // column t is final for this row: written by this thread just above
-                    pb[2] = mb[r];
-                }
-            }
-        }
-        if (tid == GP_NB - 1) EP_STAMP(4 * t + 2);
-        __syncthreads();
-        if (tid == GP_NB) EP_STAMP(4 * t + 3);
-        if (boundary && t + 1 < bsz) {
-            // the chunk is complete (column t became final above, c_t is known): mean for site t, then the chunk's 16 columns are
-            // applied to every later column of the block on the matrix cores -- tiles (I, J), jc <= J <= I < 8, J < jtiles
-            if (rowthread && r > t) mb[r] = fma(Sb[r + t * LS], cf[t], mb[r]);
-            // Only tile column jc -- the next chunk's own columns -- is needed now: its 8 - jc tiles go one to a wave.  The tile
-            // columns to the right of it are not read before THEIR chunk starts, so waves 4-7 apply this chunk to them one tile
-            // per site iteration while the next chunk's sites run (at most 21 tiles against 4 x 16 slots).
-            const int jc = (t + 1) >> 4;
-            if (jc + wave < 8 && jc < jtiles) ep_chunk_tile(A, cs, LS, jc + wave, jc, cs0, fr, fg);
-            dcs0 = cs0, dJ0 = jc + 1;
-            __syncthreads();
-            if (tid == t + 1) {   // site t+1 starts a chunk: nothing pending on its column
-                double *pb = pub + 3 * ((t + 1) & 1);
-                pb[0] = A[(t + 1) + (t + 1) * LS];
-                pb[1] = 0.0;
-                pb[2] = mb[t + 1];
-            }
-            __syncthreads();
-        }
-    }
-    if (tid == GP_NB + 64 && bsz > 0) {   // outputs of the last site (the loop ended on a barrier)
-        const double *o = ob + 5 * ((bsz - 1) & 1);
-        const double tc = o[0] - o[1];
-        const double isg = rcp_nr(o[2]);
-        const double dtau = isg - tc - o[1];
-        tb[bsz - 1] = o[1] + dtau;
-        nb[bsz - 1] = o[3] * isg - o[4];
-        ctb[bsz - 1] = tc;
-        cnb[bsz - 1] = o[4];
-    }
-    __syncthreads();
-    if (rowthread && r < bsz) {   // the block's results, in one go
-        tau[i0 + r] = tb[r];
-        nu[i0 + r] = nb[r];
-        cav_tau[i0 + r] = ctb[r];
-        cav_nu[i0 + r] = cnb[r];
-        cvec[r] = cs[r];
-        ncoef[r] = cf[r];
-    }
-    // column bsz-1 became final in the last iteration unless the block has a single site or ends on a chunk's first site
-    if (rowthread) {
-        if (r >= bsz) { cvec[r] = 0.0; ncoef[r] = 0.0; }
-        for (int c = 0; c < GP_NB; ++c)
-            Lmat[r + (size_t)c * GP_NB] = (r == c) ? 1.0 : ((r > c && c < bsz) ? Sb[r + c * LS] * cs[c] : 0.0);
-    }
-    // inverses of Lmat's eight 16 x 16 diagonal tiles (unit lower), the form the row-panel solve consumes (tile q at
-    // Ldinv + 256 q, element (c, k) at c + 16 k): forward substitution against the identity, here instead of in a launch of
-    // its own between the block kernel and the solve.  Waves 2 and 3 (idle while the row threads write Lmat) take four tiles each.
-    if (wave == 2 || wave == 3) {
-        // tiles 4 (wave - 2) + fg: the four 16-lane rows of a wave take one tile each; row owner = column owner = lane & 15, the
-        // tile's rows in registers, every cross-lane operand a DPP row broadcast (dpp_tile.h) -- no LDS traffic, no chain of loads
-        const int c0 = 16 * (4 * (wave - 2) + fg);
-        double row[16], sv[16], x[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            row[k] = (c0 + k < bsz) ? Sb[(c0 + fr) + (c0 + k) * LS] * cs[c0 + k] : 0.0;   // only k < fr is used
-            sv[k] = (k == fr) ? 1.0 : 0.0;
-        }
-        tile_unit_inverse<0>(row, sv, x);
-#pragma unroll
-        for (int rr = 0; rr < 16; ++rr) Ldinv[(c0 / 16) * 256 + rr + 16 * fr] = x[rr];
-    }
-}
-
-// ---- the same block of sites with the site loop on ONE wave and no barrier per site (GPCORE_EP_BLOCK=1, default) ----
-// In ep_block_kernel a site iteration is ~1950 cycles of which the chain of dependent fp64 operations is ~1100: the rest is the
-// barrier and the LDS hand-overs between the scalar lane and the row threads on either side of it.  Here one wave owns all 128
+// ---- the block of sites with the site loop on ONE wave and no barrier per site ----
+// (Rounds 1-2 ran the site loop on a scalar lane with two waves of row threads behind it and one barrier per site: ~1950 cycles per
+// site of which the chain of dependent fp64 operations is ~1100, the rest barrier and LDS hand-overs; that kernel, ep_block_kernel, was
+// removed in round 4.)  Here one wave owns all 128
 // rows (lane l: rows l and l + 64) and the values a site needs from "its" row are lane broadcasts (v_readlane), so a site costs
 // its chain plus a handful of instructions; everything that does not depend on the site's result -- the part of the next column
 // that comes from the chunk's earlier sites -- is independent code in the same instruction stream and fills the issue slots the
@@ -439,7 +193,12 @@ __device__ __forceinline__ void ep_site_steps(ep_site_regs &st, double *A, doubl
                     st.p0 = q0, st.p1 = q1;
                 }
             }
-            // the site chain (tilted moments only; see ep_block_kernel)
+            // The serial chain carries the tilted moments only.  With sigma^2 = sii, the new marginal variance sg and mean mi:
+            //   c = 1/(1/dtau + sii) = (sii - sg)/sii^2,   coef = dnu - c (mui + dnu sii) = (mi - mui)/sii
+            // (substitute dtau = 1/sg - 1/sii, dnu = mi/sg - mui/sii): no reciprocal of sg, of dtau or of 1 + dtau sii on
+            // the chain, and the cavity variance 1/(1/sii - to) = sii/(1 - to sii) is ONE reciprocal deep instead of two.
+            // (The reference's IEEE edge cases come out the same: dtau = 0 gives sg = sii, c = 0; sii^2 = inf gives c = NaN where the
+            // reference has 1/(1/dtau + sii) = 1/0 = inf and a covariance of NaN from there -- tests/test_gpu_ep_edge_cases.py.)
             const double rs = rcp_nr(sii);
             const double cvr = sii * rcp_nr(fma(-to, sii, 1.0));
             const double nc = fma(mui, rs, -no);
@@ -564,7 +323,7 @@ __global__ __launch_bounds__(64 * EP_BLOCK1_WAVES) void ep_block1_kernel(int n, 
         for (int c = 0; c < GP_NB; ++c)
             Lmat[r + (size_t)c * GP_NB] = (r == c) ? 1.0 : ((r > c && c < bsz) ? A[r + c * LS] * cs[c] : 0.0);
     }
-    if (wave == 2 || wave == 3) {   // unit-lower tile inverses of Lmat, as in ep_block_kernel
+    if (wave == 2 || wave == 3) {   // unit-lower tile inverses of Lmat
         const int c0 = 16 * (4 * (wave - 2) + fg);
         double row[16], sv[16], x[16];
 #pragma unroll
@@ -1093,7 +852,6 @@ __global__ __launch_bounds__(1024) void ep_lml_kernel(int n, int ldl, const doub
     if (threadIdx.x == 0) out[0] = red[0];
 }
 
-constexpr int EP_BLOCK_LDS = (GP_NB * (GP_NB + 1) + 8 * GP_NB + 32) * (int)sizeof(double);
 inline dim3 g1(int n) { return dim3((n + 255) / 256); }
 
 // out[i] = sum_j A(i,j) x[j] for rows i in [lo, lo + m) of a SYMMETRIC n x n matrix of which only the lower triangle is stored
@@ -1214,7 +972,6 @@ gp_status ep_alloc(gp_ctx *ctx, int n, const int32_t *y, gp_ep **out, int G = 1)
     *out = nullptr;
     for (int i = 0; i < n; ++i) GP_REQUIRE(ctx, y[i] == 1 || y[i] == -1, "targets must contain values from set {-1,1}");
     GP_HIP(ctx, hipSetDevice(ctx->device));
-    GP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(ep_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, EP_BLOCK_LDS));
     GP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(ep_block1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, EP_BLOCK1_LDS));
     GP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(ep_block2_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, EP_BLOCK2_LDS));
     GP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(ep_block2_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, EP_BLOCK2_LDS));
@@ -1270,29 +1027,20 @@ gp_status ep_start(gp_ep *ep) {
 }
 
 // Block pb = b - 1's delayed update of the trailing covariance, enqueued on `st` in iteration b (i0 = 128 b: first row / column that
-// still matters).  two == false: Sigma[i0:, i0:] -= Sc S^T (lower), rank 128, everything at once.  two == true (two-level, EP_OUTER
-// columns per outer panel): the rank-128 update only reaches the "near" columns [i0, nl), nl = one block past pb's outer panel -- the
-// columns the chain reads before that panel is complete --, and when pb closes its panel ONE rank-EP_OUTER update brings in
-// everything to the right of nl: a quarter of the read-modify-write traffic on those columns and a GEMM shape (K = 512) that runs at
-// twice the rate of K = 128.  Sc holds the panel's scaled columns side by side (block pb in column block pb % 4), S is in place in
-// Sigma's dead column panels.  bt: lockstep batch (strides A = Sc, B = C = Sigma).
-void ep_trailing_update(gp_ctx *ctx, hipStream_t st, int np, int i0, bool two, double *Sc, double *Sig, gp_batch bt, int *uflag = nullptr) {
+// still matters): Sigma[i0:, i0:] -= Sc S^T (lower), rank 128, everything at once.  Sc holds the scaled columns (block pb in column
+// block pb % 4 of its buffer), S is in place in Sigma's dead column panels.  bt: lockstep batch (strides A = Sc, B = C = Sigma).
+// (A two-level form -- rank-128 updates on the columns the chain reads next, one rank-512 update per outer panel for the rest -- was
+// measured equal in a batch, 228.9 vs 229.1 sweeps/s aggregate, and slower in a single run, 184.7 vs 188.0: the site loop's updates are
+// an eighth of a sweep's flops.  Removed in round 4.)
+void ep_trailing_update(gp_ctx *ctx, hipStream_t st, int np, int i0, double *Sc, double *Sig, gp_batch bt, int *uflag = nullptr) {
     const int pb = i0 / GP_NB - 1, jb = pb % (EP_OUTER / GP_NB);
-    const int P0 = pb / (EP_OUTER / GP_NB) * EP_OUTER, pe = std::min(np, P0 + EP_OUTER);
-    const int nl = two ? std::min(np, pe + GP_NB) : np;
-    const int M = np - i0, N = nl - i0;
+    const int M = np - i0;
     if (M <= GP_NB) return;          // block b is the last one: nothing below or right of it
-    const double tiles = (double)(N / GP_NB) * (M / GP_NB) - (double)(N / GP_NB) * (N / GP_NB - 1) / 2.0;
+    const double tiles = (double)(M / GP_NB) * (M / GP_NB) - (double)(M / GP_NB) * (M / GP_NB - 1) / 2.0;
     gp_prof_begin(ctx, GP_PROF_GEMM, st);
-    gpk_gemm_nt(st, M, N, GP_NB, -1.0, Sc + (size_t)jb * GP_NB * np + i0, np, Sig + (size_t)i0 + (size_t)(i0 - GP_NB) * np, np, 1.0,
+    gpk_gemm_nt(st, M, M, GP_NB, -1.0, Sc + (size_t)jb * GP_NB * np + i0, np, Sig + (size_t)i0 + (size_t)(i0 - GP_NB) * np, np, 1.0,
                 Sig + (size_t)i0 + (size_t)i0 * np, np, 1, 0, bt, nullptr, 0, uflag);
     gp_prof_end(ctx, GP_PROF_GEMM, bt.count * tiles * 2.0 * GP_NB * GP_NB * GP_NB, st);
-    if (two && i0 == pe && nl < np) {
-        const int R = np - nl, Kp = pe - P0;
-        gp_prof_begin(ctx, GP_PROF_SYRK, st);
-        gpk_gemm_nt(st, R, R, Kp, -1.0, Sc + nl, np, Sig + (size_t)nl + (size_t)P0 * np, np, 1.0, Sig + (size_t)nl + (size_t)nl * np, np, 1, 0, bt);
-        gp_prof_end(ctx, GP_PROF_SYRK, (double)bt.count * R * ((double)R + GP_NB) * Kp, st);
-    }
 }
 
 // ---- lockstep batch: G EP problems of one size advance through a sweep together (MeshHyperParamsLogLikelihoodEvaluator.scala:26-40
@@ -1372,9 +1120,6 @@ gp_status ep_sweep_lockstep(ep_slab &sl, int count) {
     // 12 problems, K = 256 / 512 / 1024: 229 / 239 / 244 sweeps/s aggregate)
     const int sig_blocks = [np] { const int v = gp_env_blocks("GPCORE_EP_SIG_K"); return v >= GP_NB ? v / GP_NB : (np >= 4096 ? 8 : 2); }();
     const bool far_split = [] { const char *e = getenv("GPCORE_EP_FAR"); return !e || atoi(e) != 0; }();
-    // two-level delayed updates (ep_trailing_update): measured equal (n = 4096, 12 problems: 228.9 vs 229.1 sweeps/s aggregate; a single
-    // run 184.7 vs 188.0) -- the site loop's updates are an eighth of a sweep's flops -- so the one-level form stays the default
-    const bool two = [] { const char *e = getenv("GPCORE_EP_TWOLEVEL"); return e && atoi(e) != 0; }();
     ep_strides es;
     es.sig = sl.sMat(), es.vec = sl.sVec(), es.y = 0, es.blk = sl.sBlk(), es.cvec = sl.sCv(), es.sc = sl.sSc(), es.flag = sl.sFlag();
     gp_batch bSig, bTrsm, bVt;
@@ -1427,7 +1172,7 @@ gp_status ep_sweep_lockstep(ep_slab &sl, int count) {
             // second stream: block b-1's trailing update of every problem, after every problem's flag
             if (np - i0 > GP_NB) {
                 hipLaunchKernelGGL(ep_wait_flag_kernel, dim3(count), dim3(1), 0, s2, e0->flags + b, sl.sFlag(), token, flag_err);
-                ep_trailing_update(ctx, s2, np, i0, two, e0->Sc, e0->Sig, bSig);
+                ep_trailing_update(ctx, s2, np, i0, e0->Sc, e0->Sig, bSig);
             }
             GP_HIP(ctx, hipEventRecord(e0->ev[4 * (b - 1) + 2], s2));
             last_side = e0->ev[4 * (b - 1) + 2];
@@ -1491,26 +1236,21 @@ gp_status gp_ep_sweep(gp_ep *ep, int nsweeps, double *tau, double *nu, int *info
     // launches are faster (the single workgroup is bound by one CU's matrix pipe: n = 4096 end-of-sweep form 106.9 vs 103.3 sweeps/s),
     // under the streamed refactorisation's GEMMs the fused one is (167.4 vs 163.9) -- so it follows `pipe` (GPCORE_EP_LINK overrides)
     const bool fused_link = [pipe] { const char *e = getenv("GPCORE_EP_LINK"); return e ? atoi(e) != 0 : pipe; }();
-    const bool block1 = [] { const char *e = getenv("GPCORE_EP_BLOCK"); return !e || atoi(e) != 0; }();   // site loop on one wave (0: one barrier per site)
     // GPCORE_EP_FUSED: the link of block b-1 is the prologue of block b's kernel (ep_block2_kernel) -- one launch per block on the
     // chain; 0: block kernel + link kernel (the form it is tested against, bit for bit).  Measured (sweeps/s fused / two launches):
     // n = 4096 181.0 / 182.1, n = 2048 425.5 / 411.8, n = 1024 627.0 / 668.3 -- the prologue costs what the link kernel did (34 us:
     // profiles/r03_c_sweep_fused.txt), the chain is as much bound by the side stream's solve + updates as by its own kernels, so
     // the default follows the streamed refactorisation (np > 1024); the lockstep batch (ep_sweep_lockstep) always uses it
-    const bool fused = overlap && block1 && [pipe] { const char *e = getenv("GPCORE_EP_FUSED"); return e ? atoi(e) != 0 : pipe; }();
-    // two-level delayed updates (ep_trailing_update): GPCORE_EP_TWOLEVEL = 1; off by default (measured equal or slower: ep_sweep_lockstep)
-    const bool two = fused && [] { const char *e = getenv("GPCORE_EP_TWOLEVEL"); return e && atoi(e) != 0; }();
+    const bool fused = overlap && [pipe] { const char *e = getenv("GPCORE_EP_FUSED"); return e ? atoi(e) != 0 : pipe; }();
     int *flag_err = ep->flags + np / GP_NB;
     if (fused) GP_HIP(ctx, hipMemsetAsync(flag_err, 0, sizeof(int), s));
-    // urgent tiles (see the launch of ep_block2_kernel below); not with the two-level updates (their rank-128 part may be narrower than
-    // two tile columns)
-    const bool urgent = fused && !two && [] { const char *e = getenv("GPCORE_EP_URGENT"); return !e || atoi(e) != 0; }();
+    // urgent tiles (see the launch of ep_block2_kernel below)
+    const bool urgent = fused && [] { const char *e = getenv("GPCORE_EP_URGENT"); return !e || atoi(e) != 0; }();
     const bool far_split = [] { const char *e = getenv("GPCORE_EP_FAR"); return !e || atoi(e) != 0; }();
     // columns of Vt per next-covariance update (GPCORE_EP_SIG_K; n = 4096 sweeps/s at 128 / 256 / 384 / 512 / 1024 / 2048: 173 / 181 / 175 / 177 /
     // 172 / 155 -- short enough to spread the fourth stream's load evenly, long enough for the GEMM)
     // (n = 8192: 29.3 sweeps/s at K = 512 against 28.0 at 256, n = 2048: 423 against 406 -- 512 from np = 6144 on)
     const int sig_blocks = [np] { const int v = gp_env_blocks("GPCORE_EP_SIG_K"); return v >= GP_NB ? v / GP_NB : (np >= 6144 ? 4 : 2); }();
-    const bool sig_small = [] { const char *e = getenv("GPCORE_EP_SIG_K128"); return e && atoi(e) != 0; }();
     const int nblk = np / GP_NB;
     double *partial = nullptr;
     if (pipe) {
@@ -1521,8 +1261,6 @@ gp_status gp_ep_sweep(gp_ep *ep, int nsweeps, double *tau, double *nu, int *info
         }
         GP_TRY(gpi_ws_get(ctx, WS_PARTIAL, sizeof(double) * (size_t)(SYMV_CHUNKS + 1) * np, &partial));
     }
-    const bool host_time = [] { const char *e = getenv("GPCORE_EP_HOSTTIME"); return e && atoi(e) != 0; }();   // lab: host time spent enqueueing the sweeps
-    const auto host_t0 = std::chrono::steady_clock::now();
     for (int sw = 0; sw < nsweeps; ++sw) {
         const int token = ++ep->epoch;
         const int utarget = urgent ? ++ep->uepoch : 0;
@@ -1579,11 +1317,8 @@ gp_status gp_ep_sweep(gp_ep *ep, int nsweeps, double *tau, double *nu, int *info
                 else
                     hipLaunchKernelGGL(ep_block2_kernel<false>, dim3(1), dim3(64 * EP_BLOCK1_WAVES), EP_BLOCK2_LDS, s, n, np, i0, bsz, ep->Sig, ep->vec,
                                        ep->y, ep->blk, ep->cvec, ep->Sc, ep->flags, par, token, ep_strides(), 0, nullptr, 0, nullptr);
-            } else if (block1)
+            } else
                 hipLaunchKernelGGL(ep_block1_kernel, dim3(1), dim3(64 * EP_BLOCK1_WAVES), EP_BLOCK1_LDS, s, n, np, i0, bsz, ep->Sig, ep->mu(), ep->y,
-                                   ep->tau(), ep->nu(), ep->cav_tau(), ep->cav_nu(), cvec, ncoef, Lmat, bdinv);
-            else
-                hipLaunchKernelGGL(ep_block_kernel, dim3(1), dim3(64 * EP_BLOCK_WAVES), EP_BLOCK_LDS, s, n, np, i0, bsz, ep->Sig, ep->mu(), ep->y,
                                    ep->tau(), ep->nu(), ep->cav_tau(), ep->cav_nu(), cvec, ncoef, Lmat, bdinv);
             hipEvent_t ev_fac = ep->ev[4 * b], ev_rows = ep->ev[4 * b + 1], ev_side = ep->ev[4 * b + 2], ev_vt = ep->ev[4 * b + 3];
             if (overlap) GP_HIP(ctx, hipEventRecord(ev_fac, s));
@@ -1602,8 +1337,7 @@ gp_status gp_ep_sweep(gp_ep *ep, int nsweeps, double *tau, double *nu, int *info
                     const int kw = i0 + GP_NB - pend0;
                     const double *Vb = ep->L + np + (size_t)pend0 * ep->ldl;
                     gp_prof_begin(ctx, GP_PROF_SYRK, s4);
-                    if (pend0 > 0 && sig_small) gpk_gemm_k128_sub(s4, np, np, Vb, ep->ldl, Vb, ep->ldl, ep->Sig2, np, 1, kw);
-                    else gpk_gemm_nt(s4, np, np, kw, -1.0, Vb, ep->ldl, Vb, ep->ldl, 1.0, ep->Sig2, np, 1, 0, gp_batch(), pend0 == 0 ? ep->K : nullptr, np);
+                    gpk_gemm_nt(s4, np, np, kw, -1.0, Vb, ep->ldl, Vb, ep->ldl, 1.0, ep->Sig2, np, 1, 0, gp_batch(), pend0 == 0 ? ep->K : nullptr, np);
                     gp_prof_end(ctx, GP_PROF_SYRK, (double)np * ((double)np + GP_NB) * kw, s4);
                     pend0 = i0 + GP_NB;
                 }
@@ -1619,7 +1353,7 @@ gp_status gp_ep_sweep(gp_ep *ep, int nsweeps, double *tau, double *nu, int *info
                 // (solve, wait, update), not on five.
                 if (np - i0 > GP_NB) {
                     hipLaunchKernelGGL(ep_wait_flag_kernel, dim3(1), dim3(1), 0, s2, ep->flags + b, 0, token, flag_err);
-                    ep_trailing_update(ctx, s2, np, i0, two, ep->Sc, ep->Sig, gp_batch(), urgent ? ep->uflags + (b - 1) : nullptr);
+                    ep_trailing_update(ctx, s2, np, i0, ep->Sc, ep->Sig, gp_batch(), urgent ? ep->uflags + (b - 1) : nullptr);
                 }
                 GP_HIP(ctx, hipEventRecord(ep->ev[4 * (b - 1) + 2], s2));
                 last_side = ep->ev[4 * (b - 1) + 2];
@@ -1680,10 +1414,7 @@ gp_status gp_ep_sweep(gp_ep *ep, int nsweeps, double *tau, double *nu, int *info
         ep->sweeps += 1;
     }
     GP_TRY(ep_join_side(ep));
-    if (host_time && nsweeps > 0)   // (n = 4096: 1.6 ms of host time per 5 ms sweep -- the host runs three sweeps ahead of the GPU; not launch-bound)
-        fprintf(stderr, "gp_ep_sweep: %d sweeps enqueued in %.3f ms of host time (%.1f us per sweep)\n", nsweeps,
-                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count(),
-                std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - host_t0).count() / nsweeps);
+    // (host time spent enqueueing, measured in round 3: 1.6 ms per 5 ms sweep at n = 4096 -- the host runs three sweeps ahead of the GPU; not launch-bound)
     int h = 0;
     GP_TRY(gpi_read_info(ctx, &h));
     if (fused) {
@@ -1900,6 +1631,7 @@ static gp_status ep_eval_lockstep(gp_ctx *ctx, const double *X, int n, int d, in
     double *dX = nullptr;
     gp_status st = gpi_ws_get(ctx, WS_A, sizeof(double) * (size_t)n * d, &dX);
     if (st == GP_OK) st = gpi_upload_2d(ctx, dX, n, X, ldx, n, d);
+    if (st == GP_OK) gpk_centroid(ctx->stream, dX, n, d, n, gp_gram_center(ctx));      // one centre for every setting of the call
     std::vector<int> slot_b(G, -1), slot_j(G, 0);
     std::vector<double> cur((size_t)G * 2 * n, 0.0), old((size_t)G * 2 * n, 0.0), pull((size_t)G * 2 * np);
     std::vector<int> hinfo(G, 0);
@@ -1909,7 +1641,7 @@ static gp_status ep_eval_lockstep(gp_ctx *ctx, const double *X, int n, int d, in
         if (next >= B) return GP_OK;
         const int b = next++;
         gp_ep *v = sl.ep[g];
-        gpk_gram_sym(ctx->stream, dX, n, d, n, thetas + (size_t)b * P, v->K, np, 1, 0.0, gp_gram_flag(ctx));
+        gpk_gram_sym(ctx->stream, dX, n, d, n, thetas + (size_t)b * P, v->K, np, 1, 0.0, gp_gram_flag(ctx), gp_gram_center(ctx));
         GP_TRY(ep_start(v));
         slot_b[g] = b, slot_j[g] = 0;
         std::fill(cur.begin() + (size_t)g * 2 * n, cur.begin() + (size_t)(g + 1) * 2 * n, 0.0);
@@ -2004,11 +1736,12 @@ static gp_status ep_eval_batched(gp_ctx *ctx, const double *X, int n, int d, int
         double *dX = nullptr;
         if (st == GP_OK) st = gpi_ws_get(c, WS_A, sizeof(double) * (size_t)n * d, &dX);
         if (st == GP_OK) st = gpi_upload_2d(c, dX, n, X, ldx, n, d);
+        if (st == GP_OK) gpk_centroid(c->stream, dX, n, d, n, gp_gram_center(c));
         std::vector<double> tau(n), nu(n), tau_old(n), nu_old(n);
         while (st == GP_OK) {
             const int b = next.fetch_add(1);
             if (b >= B) break;
-            gpk_gram_sym(c->stream, dX, n, d, n, thetas + (size_t)b * P, ep->K, ep->np, 1, 0.0, gp_gram_flag(c));
+            gpk_gram_sym(c->stream, dX, n, d, n, thetas + (size_t)b * P, ep->K, ep->np, 1, 0.0, gp_gram_flag(c), gp_gram_center(c));
             st = ep_start(ep);
             int j = 0, h = 0;
             std::fill(tau.begin(), tau.end(), 0.0);

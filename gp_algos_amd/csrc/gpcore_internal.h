@@ -47,10 +47,6 @@ struct gp_ctx {
     // scratch reused across calls
     double *d_scalars = nullptr;  // small device scratch (256 doubles)
     int *d_info = nullptr;        // device-side failing-pivot flag
-    // fused diagonal chain of single factorisations (chol_blocked): per-step flags + error word, per-step events, token
-    int *d_cflags = nullptr;
-    int cflags_cap = 0, chol_epoch = 0;
-    std::vector<hipEvent_t> chol_ev;
 };
 
 struct gp_model {
@@ -60,6 +56,7 @@ struct gp_model {
     bool has_x = false;              // false for gp_fit_from_gram
     int kind = 0;                    // kernel the model rebuilds Gram matrices with: 0 = ARD-RBF (theta = d + 2), 1 = Co2Kernel (d = 1, theta = 11)
     double *dX = nullptr;            // n x d, ld = n
+    double *dcen = nullptr;          // d: centroid of the rows of dX (centre of the matrix-core Gram forms), set with dX
     double *dy = nullptr;            // np
     double *dL = nullptr;            // (np + GP_NB) x np, ld = ldl; row np holds y^T -> (L^-1 y)^T
     double *dalpha = nullptr;        // np
@@ -107,8 +104,7 @@ void gpk_gemm_nt(hipStream_t s, int M, int N, int K, double alpha, const double 
                  int *uflag = nullptr);   // single lower products: *uflag += 1 (release) when tile (1,0) / (1,1) is stored, by two workgroups at the head of the grid
 // C (M x N; lower != 0: the lower trapezoid, i >= j on its diagonal tiles) -= A (M x 128) B (N x 128)^T (K a multiple of 32) on 64 x 64 tiles: the
 // latency-bound updates of a single factorisation -- few 128 x 128 tiles, short K (M, N multiples of 64)
-void gpk_gemm_k128_sub(hipStream_t s, int M, int N, const double *A, int lda, const double *B, int ldb, double *C, int ldc, int lower, int K = 128,
-                       int skip_rows = 0);   // tiles whose first row is < skip_rows are left alone
+void gpk_gemm_k128_sub(hipStream_t s, int M, int N, const double *A, int lda, const double *B, int ldb, double *C, int ldc, int lower, int K = 128);
 // C[M x 128] = A[M x K] * B[128 x K]^T with fused row reductions (sumsq[m] += sum_n C(m,n)^2, dots[m] += sum_n C(m,n) tvec[n]);
 // C may be the last 128 columns of A (in-place posterior step).
 void gpk_gemm_nt_rowred(hipStream_t s, int M, int N, int K, const double *A, int lda, const double *B, int ldb, double *C, int ldc,
@@ -116,10 +112,17 @@ void gpk_gemm_nt_rowred(hipStream_t s, int M, int N, int K, const double *A, int
 // ARD-RBF Gram.  theta on host.  symmetric: Xb == Xa, noise on the diagonal, tiles bi >= bj only (mirrored if full).
 // far_flag: one int of device memory owned by the caller's context and used in stream order (gp_gram_flag(ctx)); nullptr = the per-pair
 // kernel without the scan
-void gpk_gram_sym(hipStream_t s, const double *X, int n, int d, int ldx, const double *theta, double *K, int ldk, int full, double extra_diag, int *far_flag);
+// center: d doubles on the device (gpk_centroid of the training points; what z = (x - c) / l of the matrix-core forms is taken against), or
+// nullptr = the first point
+void gpk_gram_sym(hipStream_t s, const double *X, int n, int d, int ldx, const double *theta, double *K, int ldk, int full, double extra_diag, int *far_flag,
+                  const double *center = nullptr);
+void gpk_centroid(hipStream_t s, const double *X, int n, int d, int ldx, double *c);
 void gpk_dgram_sym(hipStream_t s, const double *X, int n, int d, int ldx, const double *theta, int pos, double *D, int ldd);
-void gpk_gram_cross(hipStream_t s, const double *Xs, int m, int ldxs, const double *X, int n, int ldx, int d, const double *theta, double *Ks, int ldks, int *far_flag);
+void gpk_gram_cross(hipStream_t s, const double *Xs, int m, int ldxs, const double *X, int n, int ldx, int d, const double *theta, double *Ks, int ldks, int *far_flag,
+                    const double *center = nullptr);
 inline int *gp_gram_flag(gp_ctx *ctx) { return ctx->d_info + 4; }     // d_info holds 8 ints: [0..3] factorisation status, [4] the Gram scan's flag
+// per-call centre of a Gram build whose inputs no model owns (GP_DMAX doubles behind the 8 ints of d_info, used in stream order)
+inline double *gp_gram_center(gp_ctx *ctx) { return reinterpret_cast<double *>(ctx->d_info + 8); }
 // Co2Kernel (gp/regression/Co2Prediction.scala:29-137), 1-D inputs, theta = hp1..hp11 on the host; pos = 0: kernel, 1..11: derivative
 void gpk_co2_gram(hipStream_t s, const double *xr, int nr, const double *xc, int nc, const double *theta, int pos, double *K, int ldk, int sym,
                   int full, double extra);
@@ -159,10 +162,6 @@ int gpk_init_gemm_kernels();
 // MFMA-blocked critical-path kernels (kernels_diag.hip).  dinv holds the inverses of the 16x16 diagonal
 // tiles of L: tile b (rows 16b..16b+15) at dinv + 256*b, element (c,k) at c + 16k; a 128-block owns 8 tiles.
 void gpk_potrf_diag128(hipStream_t s, double *A, int lda, double *dinv_k, int *d_info, int base, gp_batch bt = gp_batch());   // strides: A, dinv; d_info + 1 per problem
-// the same with the link to the step before as its prologue (A = block (k, k), k >= 1: solves A[blk k, blk k-1] against the previous
-// diagonal block in place, applies it to the block, sets *flag = token when the solved rows are in memory), and the bounded wait
-void gpk_potrf_link128(hipStream_t s, double *A, int lda, double *dinv_k, int *d_info, int base, int *flag, int token);
-void gpk_chol_wait_flag(hipStream_t s, const int *flag, int token, int *err);
 // optional fused row reductions: sumsq[p] += sum_c X(p,c)^2 ; dots[p] += sum_c X(p,c) tvec[c]
 // EP: the 128 rows of the delayed columns that belong to the next site block (X <- X Lmat^-T in place, X2 = X diag(cs2), dots += X tvec)
 // and the 128 x 128 lower tile D -= X2 X^T the next block kernel reads, one workgroup (kernels_diag.hip)

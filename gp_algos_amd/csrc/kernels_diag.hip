@@ -103,7 +103,7 @@ __device__ unsigned long long potrf_stamps[256];
 
 // -------------------------------------------------------------------------------------------------
 constexpr int POTRF_WAVES = 8;   // wave 0: the serial chain; the others: panel, update and stores (two waves per SIMD hide each other's LDS / MFMA latency)
-// The factorisation proper of potrf_diag128_kernel / potrf_link128_kernel: the 128 x 128 block is in LDS (a, column stride PLS; the
+// The factorisation proper of potrf_diag128_kernel: the 128 x 128 block is in LDS (a, column stride PLS; the
 // part on and below the diagonal is enough), every wave's share of it has landed before the call (the first barrier inside orders
 // the waves).  Writes L (zeros above the diagonal) and the eight tile inverses to global memory as it goes.
 __device__ __forceinline__ void potrf_block_body(double *a, double *dv, int *flag, double *__restrict__ A, int lda, double *__restrict__ dinv,
@@ -412,122 +412,6 @@ __global__ __launch_bounds__(512) void ep_link_kernel(double *__restrict__ X, in
     }
 }
 
-// -------------------------------------------------------------------------------------------------
-// One launch per step of a single factorisation's diagonal chain: the link to the step before -- this block's 128 rows of the previous
-// block column solved against the previous diagonal block, X = A[blk k, blk k-1] L_{k-1,k-1}^-T, and this block's own update
-// D = A[blk k, blk k] -= X X^T -- as the PROLOGUE of the diagonal-block factorisation, instead of being parts of the panel solve and
-// of the in-panel update, two more launches between two diagonal blocks.  The strip is solved in the LDS the factorisation is about to
-// use (same 144-double column stride), the 36 lower tiles of D are updated in registers and dropped into that LDS image; X goes back
-// in place and is announced by a device flag (release, agent scope) so that the side stream's update of the rest of the panel -- which
-// multiplies by these rows -- starts while this kernel factors.  A is the block (k, k); the strip, the previous diagonal block and its
-// tile inverses are found relative to it.
-__global__ __launch_bounds__(64 * POTRF_WAVES) void potrf_link128_kernel(double *__restrict__ A, int lda, double *__restrict__ dinv, int *info, int base,
-                                                                        int *__restrict__ flag_out, int token) {
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    double *a = sm;                 // NB x PLS: first the strip X, then the block D
-    double *dv = sm + NB * PLS;
-    int *flag = reinterpret_cast<int *>(dv + 256);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int fr = lane & 15, fg = lane >> 4;
-    if (tid == 0) *flag = 0;
-    double *X = A - (size_t)NB * lda;                       // rows of this block, columns of the block before
-    const double *Lp = A - NB - (size_t)NB * lda;           // the diagonal block before (factored) ...
-    const double *dp = dinv - 8 * 256;                      // ... and its tile inverses
-    {   // strip by LDS-DMA: one wave instruction = one 128-row column (1 KiB), 16 per wave, all in flight
-        const double *src = X + lane * 2 + (size_t)wave * lda;
-#pragma unroll
-        for (int q = 0; q < NB / 8; ++q) __builtin_amdgcn_global_load_lds(src + (size_t)(8 * q) * lda, a + (wave + 8 * q) * PLS, 16, 0, 0);
-    }
-    // this wave's tiles of D (q = wave, wave + 8, ...; at most 5): fetched now, under the solve
-    double4_t dacc[5];
-#pragma unroll
-    for (int u = 0; u < 5; ++u) {
-        const int q = wave + 8 * u;
-        int I = 0, J = 0;
-        if (q < 36) tri_coords(q, I, J);
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) dacc[u][rr] = (q < 36) ? A[(16 * I + fr) + (size_t)(16 * J + fg + 4 * rr) * lda] : 0.0;
-    }
-    double fa[28], fb[28];
-    trsm_load_frags<1>(Lp, lda, fr, fg, fa);
-    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the DMA has landed (and the loads above)
-    __syncthreads();
-    const int sp = wave * 16 + fr;        // this lane's row inside the strip: every wave solves its own 16 rows
-    double ss = 0.0;
-    trsm_load_frags<2>(Lp, lda, fr, fg, fb);
-    trsm_chunk<0, PLS>(a, sp, fr, fg, fa, dp, ss);
-    trsm_chunk<1, PLS>(a, sp, fr, fg, fa, dp, ss);
-    trsm_load_frags<3>(Lp, lda, fr, fg, fa);
-    trsm_chunk<2, PLS>(a, sp, fr, fg, fb, dp, ss);
-    trsm_load_frags<4>(Lp, lda, fr, fg, fb);
-    trsm_chunk<3, PLS>(a, sp, fr, fg, fa, dp, ss);
-    trsm_load_frags<5>(Lp, lda, fr, fg, fa);
-    trsm_chunk<4, PLS>(a, sp, fr, fg, fb, dp, ss);
-    trsm_load_frags<6>(Lp, lda, fr, fg, fb);
-    trsm_chunk<5, PLS>(a, sp, fr, fg, fa, dp, ss);
-    trsm_load_frags<7>(Lp, lda, fr, fg, fa);
-    trsm_chunk<6, PLS>(a, sp, fr, fg, fb, dp, ss);
-    trsm_chunk<7, PLS>(a, sp, fr, fg, fa, dp, ss);
-    (void)ss;
-    __syncthreads();
-    {   // the solved rows go back in place now: the stores drain while the matrix cores run the tile update
-        const int li = lane * 2, lc = wave;
-#pragma unroll 8
-        for (int q = 0; q < NB / 8; ++q)
-            *reinterpret_cast<double2_t *>(X + li + (size_t)(lc + 8 * q) * lda) = *reinterpret_cast<const double2_t *>(a + (lc + 8 * q) * PLS + li);
-    }
-    // D(lower) -= X X^T: 36 lower 16 x 16 tiles over the eight waves, K = 128, operands from the strip.  After each wave's first
-    // tile the stores have drained: announce the rows then (the helper stream's update of the rest of the panel is as much on the
-    // factorisation's critical path as this kernel), not after the whole update.
-#pragma unroll
-    for (int u = 0; u < 5; ++u) {
-        const int q = wave + 8 * u;
-        if (q < 36) {
-            int I, J;
-            tri_coords(q, I, J);
-            double4_t acc = dacc[u];
-#pragma unroll 8
-            for (int ks = 0; ks < 32; ++ks) {
-                const int k = 4 * ks + fg;
-                acc = MFMA(-a[k * PLS + 16 * J + fr], a[k * PLS + 16 * I + fr], acc);
-            }
-            dacc[u] = acc;
-        }
-        if (u == 0) {
-            __builtin_amdgcn_s_waitcnt(0x0F70);   // this wave's stores of X are acknowledged
-            __syncthreads();
-            if (tid == 64) {
-                __threadfence();
-                __hip_atomic_store(flag_out, token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-    }
-    __syncthreads();                      // nobody reads the strip any more
-#pragma unroll
-    for (int u = 0; u < 5; ++u) {
-        const int q = wave + 8 * u;
-        if (q >= 36) break;
-        int I, J;
-        tri_coords(q, I, J);
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) a[(16 * I + fr) + (16 * J + fg + 4 * rr) * PLS] = dacc[u][rr];
-    }
-    // (the first barrier of the factorisation orders these writes before anybody reads them)
-    potrf_block_body(a, dv, flag, A, lda, dinv, info, base, tid, lane, wave, fr, fg);
-}
-
-// One thread waits for the flag potrf_link128_kernel sets when its solved rows are in memory.  Bounded: the producer was launched
-// before this kernel and depends on nothing that comes after it; on a time-out the failing-pivot word `err` becomes -1, which
-// read_info turns into GP_EHIP.  A word that is already non-zero (a non-positive pivot earlier on: the result is lost anyway, or a
-// time-out) ends the wait at once.
-__global__ void chol_wait_flag_kernel(const int *__restrict__ f, int token, int *__restrict__ err) {
-    int it = 0;
-    while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != token) {
-        if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-        if (++it > 200000) { atomicCAS(err, 0, -1); break; }
-        __builtin_amdgcn_s_sleep(32);
-    }
-}
 
 // -------------------------------------------------------------------------------------------------
 // Solve the 128x128 diagonal system in LDS with the tile inverses.  a = L_kk (NB x LS1), v = rhs (NB), in place.
@@ -645,7 +529,6 @@ int gpk_init_diag_kernels() {
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(trsm_panel128_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, TRSM_LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(trsm_panel128_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, TRSM_LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(ep_link_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LINK_LDS);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(potrf_link128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, POTRF_LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(fwd_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, STEP_LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(bwd_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, STEP_LDS);
     return e == hipSuccess ? 0 : 1;
@@ -662,12 +545,6 @@ void gpk_trsm_panel128(hipStream_t s, double *X, int M, int ldx, const double *L
         hipLaunchKernelGGL(trsm_panel128_kernel<true>, dim3(M / 64, bt.count), dim3(256), TRSM_LDS, s, X, ldx, Lkk, ldl, dinv, sumsq, tvec, dots, bt, X2, cs2);
     else
         hipLaunchKernelGGL(trsm_panel128_kernel<false>, dim3(M / 64, bt.count), dim3(256), TRSM_LDS, s, X, ldx, Lkk, ldl, dinv, sumsq, tvec, dots, bt, X2, cs2);
-}
-void gpk_potrf_link128(hipStream_t s, double *A, int lda, double *dinv, int *d_info, int base, int *flag, int token) {
-    hipLaunchKernelGGL(potrf_link128_kernel, dim3(1), dim3(64 * POTRF_WAVES), POTRF_LDS, s, A, lda, dinv, d_info, base, flag, token);
-}
-void gpk_chol_wait_flag(hipStream_t s, const int *flag, int token, int *err) {
-    hipLaunchKernelGGL(chol_wait_flag_kernel, dim3(1), dim3(1), 0, s, flag, token, err);
 }
 void gpk_ep_link(hipStream_t s, double *X, int ldx, const double *Lmat, const double *dinv, const double *tvec, double *dots, double *X2,
                  const double *cs2, double *D, int ldd) {

@@ -391,203 +391,6 @@ __global__ __launch_bounds__(WV * 64, 1) void gemm_fused_kernel(int M, int N, in
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------
-// Persistent-tile form of the same product for SHORT K (round 4):  C = beta*Cin + alpha * A * B^T, K = 128 ... 1024.
-//
-// With K = 128 ... 512 a 128 x 128 tile is 14 ... 55 us of MFMA issue between a prologue (first operand stage: one L2 round trip)
-// and an epilogue (read-modify-write of the 128 KB tile of C: two dependent HBM round trips) that keep the matrix pipe idle --
-// gemm_nt_f64_kernel hides them only as far as the OTHER workgroup of the CU happens to be in its k loop.  Here ONE workgroup per
-// CU (8 waves x 64 x 32, 2 waves per SIMD, up to 256 registers each) walks a list of tiles and never leaves the k loop between them:
-//   * the last k-step of tile t already stages the first operand tile of tile t+1 (the LDS ring just keeps turning);
-//   * tile t's finished accumulators move to a second register set ("held") and its epilogue is TRICKLED through the first five
-//     k-steps of tile t+1: k-step j asks for a quarter of the C tile (8 loads per lane), k-step j+1 combines and stores it.  The
-//     loads have a whole k-step (>= 1.7 us) to come back and are waited for with a COUNTED s_waitcnt (vector-memory operations
-//     complete in issue order: stores of the previous quarter, then this k-step's LDS-DMA, then the loads -- vmcnt(8) retires
-//     everything but the loads) in front of a raw s_barrier, so neither the DMA nor the barrier ever waits for HBM;
-//   * only the very last tile of a workgroup has a conventional epilogue.
-// Tile order and XCD mapping: the tiles of the launch (all problems of a lockstep batch) are cut into 8 contiguous runs, one per
-// XCD; the W workgroups of an XCD take its run round-robin (tiles t, t+W, ...), so at any moment the XCD works on W consecutive
-// tiles, which share their operand panels in that XCD's L2.  Results are bit-identical to gemm_nt_f64_kernel's (same k order per
-// element, same fma in the epilogue).
-template <int LOWER, int HAS_BETA>
-__global__ __launch_bounds__(512, 1) void gemm_pt_kernel(int M, int N, int K, double alpha, const double *__restrict__ A, int lda,
-                                                         const double *__restrict__ B, int ldb, double beta, double *__restrict__ C, int ldc,
-                                                         gp_batch bt, const double *__restrict__ Cin, int ldcin, int tiles_per_problem, int total_tiles) {
-    __shared__ __attribute__((aligned(16))) double smem[2 * 2 * TK * LDS_STRIDE];
-    double *As = smem;                          // [2][TK][LDS_STRIDE]
-    double *Bs = smem + 2 * TK * LDS_STRIDE;    // [2][TK][LDS_STRIDE]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = (wave & 1) * 64, wn = (wave >> 1) * 32;
-    const int fr = lane & 15, fk = lane >> 4;
-    // this workgroup's tiles: run [r0, r1) of its XCD, entries r0 + w, r0 + w + W, ...
-    const int xcd = blockIdx.x & 7, w = blockIdx.x >> 3;
-    const int W = ((int)gridDim.x + 7 - xcd) >> 3;
-    const int q = total_tiles >> 3, rm = total_tiles & 7;
-    const int r0 = xcd * q + (xcd < rm ? xcd : rm), r1 = r0 + q + (xcd < rm ? 1 : 0);
-    int t = r0 + w;
-    if (t >= r1) return;
-    const int nbm = M / TM, nbn = N / TN, KT = K / TK;
-    if (!Cin) { Cin = C; ldcin = ldc; bt.s3 = bt.s2; }
-
-    // a tile, as this lane sees it: LDS-DMA sources of k-row `wave`, its first element of C / Cin (m = bi*128 + wm + fr, n = bj*128 + wn + fk),
-    // and dbias = 0 on a diagonal tile of a lower product (elements with m < n are neither read nor written), a large number elsewhere
-    const double *cur_a, *cur_b, *nxt_a = nullptr, *nxt_b = nullptr, *hd_ci = nullptr, *cur_ci, *nxt_ci = nullptr;
-    double *cur_c, *nxt_c = nullptr, *hd_c = nullptr;
-    int cur_db, nxt_db = 0;
-    const int dm = wm + fr - wn - fk;     // element (mt, dn) of this lane lies above the diagonal of a diagonal tile iff dm + 16 mt < dn
-    auto locate = [&](int g, const double *&pa, const double *&pb, double *&pc, const double *&pci, int &db) {
-        const int prob = g / tiles_per_problem, tt = g - prob * tiles_per_problem;
-        int bi, bj;
-        if (LOWER) tile_coords_lower(tt, nbm, nbn, bi, bj);
-        else { bi = tt % nbm; bj = tt / nbm; }
-        pa = A + (size_t)prob * bt.s0 + (size_t)bi * TM + lane * 2 + (size_t)wave * lda;
-        pb = B + (size_t)prob * bt.s1 + (size_t)bj * TN + lane * 2 + (size_t)wave * ldb;
-        pc = C + (size_t)prob * bt.s2 + (size_t)(bi * TM + wm + fr) + (size_t)(bj * TN + wn + fk) * ldc;
-        pci = Cin + (size_t)prob * bt.s3 + (size_t)(bi * TM + wm + fr) + (size_t)(bj * TN + wn + fk) * ldcin;
-        db = (LOWER && bi == bj) ? 0 : (1 << 20);
-    };
-    auto stage = [&](int buf, const double *pa, const double *pb, int kt) {
-        const size_t koff = (size_t)kt * TK;
-#pragma unroll
-        for (int qq = 0; qq < TK / 8; ++qq) {
-            __builtin_amdgcn_global_load_lds(pa + (koff + 8 * qq) * lda, As + (buf * TK + wave + 8 * qq) * LDS_STRIDE, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(pb + (koff + 8 * qq) * ldb, Bs + (buf * TK + wave + 8 * qq) * LDS_STRIDE, 16, 0, 0);
-        }
-    };
-    int buf = 0;
-    double4_t acc[2][4], held[2][4];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) { acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0}; held[a][b] = acc[a][b]; }
-    auto mfma_block = [&](int buf) {
-        const double *Ac = As + buf * TK * LDS_STRIDE + wm + fr;
-        const double *Bc = Bs + buf * TK * LDS_STRIDE + wn + fr;
-#pragma unroll
-        for (int ks = 0; ks < TK / 4; ++ks) {
-            double af[4], bf[2];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) af[u] = Ac[(ks * 4 + fk) * LDS_STRIDE + u * 16];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) bf[u] = Bc[(ks * 4 + fk) * LDS_STRIDE + u * 16];
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
-                    acc[nt][mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[nt], af[mt], acc[nt][mt], 0, 0, 0);
-        }
-    };
-    // quarter g of the held tile: nt = g >> 1, r in {2 (g & 1), 2 (g & 1) + 1}, mt = 0..3  ->  element (m0 + 16 mt, n0 + 16 nt + 4 r).
-    // Only tiles OFF the diagonal are held (no element of theirs is masked: loads and stores are unconditional, no branch around
-    // a vector-memory instruction); a diagonal tile of a lower product gets a conventional, masked epilogue at once.
-    double cv[8];
-    auto quarter_load = [&](int g) {
-        if (!HAS_BETA) return;
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-            const int nt = g >> 1, r = 2 * (g & 1) + rr, dn = nt * 16 + 4 * r;
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) cv[rr * 4 + mt] = hd_ci[mt * 16 + (size_t)dn * ldcin];
-        }
-    };
-    auto quarter_store = [&](int g) {
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-            const int nt = g >> 1, r = 2 * (g & 1) + rr, dn = nt * 16 + 4 * r;
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                double v = alpha * held[nt][mt][r];
-                if (HAS_BETA) v = fma(beta, cv[rr * 4 + mt], v);
-                hd_c[mt * 16 + (size_t)dn * ldc] = v;
-            }
-        }
-    };
-    auto plain_step = [&](int kt, bool has_next) {
-        if (kt + 1 < KT) stage(buf ^ 1, cur_a, cur_b, kt + 1);
-        else if (has_next) stage(buf ^ 1, nxt_a, nxt_b, 0);
-        mfma_block(buf);
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this k-step's DMA has landed, this wave's fragment reads are done
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        buf ^= 1;
-    };
-
-    locate(t, cur_a, cur_b, cur_c, cur_ci, cur_db);
-    stage(0, cur_a, cur_b, 0);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    bool have_held = false;
-    for (;;) {
-        const int tn = t + W;
-        const bool has_next = tn < r1;
-        if (has_next) locate(tn, nxt_a, nxt_b, nxt_c, nxt_ci, nxt_db);
-        if (have_held) {
-            // k-steps 0..4 carry the held tile's epilogue (K >= 128: KT >= 8).  Issue order per k-step: stores of the previous quarter, the
-            // LDS-DMA of the next operand tile, the loads of this quarter; vmcnt(8) retires all but the 8 loads.
-#pragma unroll
-            for (int j = 0; j < 5; ++j) {
-                if (j >= 1) quarter_store(j - 1);
-                asm volatile("" ::: "memory");
-                stage(buf ^ 1, cur_a, cur_b, j + 1);
-                asm volatile("" ::: "memory");
-                if (j < 4) quarter_load(j);
-                asm volatile("" ::: "memory");
-                mfma_block(buf);
-                if (j < 4 && HAS_BETA) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-                buf ^= 1;
-            }
-        } else {
-            for (int kt = 0; kt < 5; ++kt) plain_step(kt, has_next);
-        }
-        for (int kt = 5; kt < KT; ++kt) plain_step(kt, has_next);
-        if (cur_db == 0) {
-            // diagonal tile: masked epilogue now (m < n is neither read nor written)
-            have_held = false;
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                double dv[4][4];
-                if (HAS_BETA) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-#pragma unroll
-                        for (int mt = 0; mt < 4; ++mt)
-                            dv[r][mt] = (dm + mt * 16 < nt * 16 + 4 * r) ? 0.0 : cur_ci[mt * 16 + (size_t)(nt * 16 + 4 * r) * ldcin];
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int mt = 0; mt < 4; ++mt) {
-                        double v = alpha * acc[nt][mt][r];
-                        if (HAS_BETA) v = fma(beta, dv[r][mt], v);
-                        if (!(dm + mt * 16 < nt * 16 + 4 * r)) cur_c[mt * 16 + (size_t)(nt * 16 + 4 * r) * ldc] = v;
-                    }
-            }
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int b = 0; b < 4; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
-        } else {
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int b = 0; b < 4; ++b) { held[a][b] = acc[a][b]; acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0}; }
-            hd_c = cur_c, hd_ci = cur_ci;
-            have_held = true;
-        }
-        if (!has_next) break;
-        cur_a = nxt_a, cur_b = nxt_b, cur_c = nxt_c, cur_ci = nxt_ci, cur_db = nxt_db;
-        t = tn;
-    }
-    // the last tile of this workgroup, if it is still held: a conventional epilogue
-    if (have_held) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) { quarter_load(g); quarter_store(g); }
-    }
-}
-
 // C -= A B^T (K a multiple of 32) on 64 x 64 tiles (4 waves x 32 x 32): the in-panel update of the blocked Cholesky
 // (A21 column block -= A21_k A21_k^T confined to one outer panel: r rows x <= 384 columns).  With the general kernel's 128 x 128
 // tiles such a launch is a few hundred workgroups of 14 us of MFMA issue each -- one round, bound by the latency of a single
@@ -597,7 +400,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pt_kernel(int M, int N, int K, do
 constexpr int SK_T = 64, SK_S = 80, SK_C = 32;
 template <int LOWER>
 __global__ __launch_bounds__(256) void gemm_k128_kernel(int M, int N, int K, const double *__restrict__ A, int lda, const double *__restrict__ B,
-                                                        int ldb, double *__restrict__ C, int ldc, int skip_rows) {
+                                                        int ldb, double *__restrict__ C, int ldc) {
     __shared__ __attribute__((aligned(16))) double as[SK_C * SK_S], bs[SK_C * SK_S];
     int bi, bj;
     const int tm = M / SK_T;
@@ -612,7 +415,6 @@ __global__ __launch_bounds__(256) void gemm_k128_kernel(int M, int N, int K, con
     }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fk = lane >> 4;
     const int i0 = bi * SK_T, j0 = bj * SK_T, wi = (wave & 1) * 32, wj = (wave >> 1) * 32;
-    if (i0 < skip_rows) return;      // rows somebody else owns (the fused Cholesky chain: the next diagonal block is its kernel's business)
     const double *Ap = A + i0 + lane + (size_t)wave * lda, *Bp = B + j0 + lane + (size_t)wave * ldb;   // thread: row `lane`, k = wave + 4 q
     double ra[SK_C / 4], rb[SK_C / 4];
 #pragma unroll
@@ -710,9 +512,8 @@ void gpk_gemm_nt(hipStream_t s, int M, int N, int K, double alpha, const double 
     // (The 256 x 128 / 16-wave tile of the posterior step was also tried here for the general launches: C3 658-663 vs 668-675
     // settings/s, C4 75.8 vs 82.3 sweeps/s -- with several column tiles per launch and short k its unhidden prologue and
     // epilogue cost more than the shared B tile saves.  Not used.)
-    // 8 waves per workgroup (64 x 32 per wave, 4 waves/SIMD at 2 workgroups/CU) measured equal to 4 waves (64 x 64 per wave) on
-    // long-K launches (65 TFLOP/s both) and ~5 % better on the short-K Cholesky updates; GPCORE_GEMM_WAVES=4 selects the other.
-    static const int nw = [] { const char *e = getenv("GPCORE_GEMM_WAVES"); return (e && atoi(e) == 4) ? 4 : 8; }();
+    // 8 waves per workgroup (64 x 32 per wave, 4 waves/SIMD at 2 workgroups/CU).  A 4-wave form (64 x 64 per wave, 178 VGPRs) measured
+    // equal on long-K launches (65 TFLOP/s both) and ~5 % worse on the short-K Cholesky updates; it was an A/B switch until round 4.
     int ntiles = lower ? ((N / TN) * (M / TM) - (N / TN) * ((N / TN) - 1) / 2) : (M / TM) * (N / TN);   // lower: trapezoid, M >= N
     int gy = bt.count;
     if (uflag) ntiles += 2;
@@ -727,47 +528,25 @@ void gpk_gemm_nt(hipStream_t s, int M, int N, int K, double alpha, const double 
         ntiles = 8 * most;
         gy = 1;
     }
-#define GP_LAUNCH(LO, HB, NWV) hipLaunchKernelGGL((gemm_nt_f64_kernel<LO, HB, NWV>), dim3(ntiles, gy), dim3(NWV * 64), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, ktri, bt, rr, Cin, ldcin, uflag)
-    if (nw == 8) {
-        if (lower) { if (hb) GP_LAUNCH(1, 1, 8); else GP_LAUNCH(1, 0, 8); }
-        else { if (hb) GP_LAUNCH(0, 1, 8); else GP_LAUNCH(0, 0, 8); }
-    } else {
-        if (lower) { if (hb) GP_LAUNCH(1, 1, 4); else GP_LAUNCH(1, 0, 4); }
-        else { if (hb) GP_LAUNCH(0, 1, 4); else GP_LAUNCH(0, 0, 4); }
-    }
+#define GP_LAUNCH(LO, HB) hipLaunchKernelGGL((gemm_nt_f64_kernel<LO, HB, 8>), dim3(ntiles, gy), dim3(512), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, ktri, bt, rr, Cin, ldcin, uflag)
+    if (lower) { if (hb) GP_LAUNCH(1, 1); else GP_LAUNCH(1, 0); }
+    else { if (hb) GP_LAUNCH(0, 1); else GP_LAUNCH(0, 0); }
 #undef GP_LAUNCH
-}
-
-// the persistent-tile kernel for short-K products (single problems and lockstep batches; no ktri, no urgent tiles)
-void gpk_gemm_nt_pt(hipStream_t s, int M, int N, int K, double alpha, const double *A, int lda, const double *B, int ldb, double beta, double *C,
-                    int ldc, int lower, gp_batch bt, const double *Cin, int ldcin, int num_cu) {
-    if (M <= 0 || N <= 0 || bt.count <= 0) return;
-    const int tpp = lower ? ((N / TN) * (M / TM) - (N / TN) * ((N / TN) - 1) / 2) : (M / TM) * (N / TN);
-    const int total = tpp * bt.count;
-    const int grid = std::min(total, num_cu > 0 ? num_cu : 256);
-    const bool hb = beta != 0.0;
-#define GP_LAUNCH_PT(LO, HB) hipLaunchKernelGGL((gemm_pt_kernel<LO, HB>), dim3(grid), dim3(512), 0, s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bt, Cin, ldcin, tpp, total)
-    if (lower) { if (hb) GP_LAUNCH_PT(1, 1); else GP_LAUNCH_PT(1, 0); }
-    else { if (hb) GP_LAUNCH_PT(0, 1); else GP_LAUNCH_PT(0, 0); }
-#undef GP_LAUNCH_PT
 }
 
 // C = A B^T (no beta) with the row reductions above; C may alias the last N columns of A (each tile reads only its own
 // rows of A and stores after its k loop) -- the in-place posterior step.
 // per device, from gp_ctx_create: the fused kernel's 106 KB of LDS is above the default dynamic limit
 int gpk_init_gemm_kernels() {
-    const bool a = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_fused_kernel<0, 0, 1, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS) == hipSuccess;
-    const bool b = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_fused_kernel<0, 0, 1, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS) == hipSuccess;
-    return (a && b) ? 0 : 1;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_fused_kernel<0, 0, 1, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS) == hipSuccess ? 0 : 1;
 }
 
 void gpk_gemm_nt_rowred(hipStream_t s, int M, int N, int K, const double *A, int lda, const double *B, int ldb, double *C, int ldc,
                         double *sumsq, const double *tvec, double *dots) {
     if (M <= 0 || N != TN) return;   // one column tile: a tile is the only writer of its rows' accumulators
-    // 256-row tiles by one 16-wave workgroup per CU where they fit (GPCORE_GEMM_FUSED=0: always two 8-wave workgroups on
-    // 128-row tiles); an odd 128-row remainder goes through the 8-wave kernel below
-    static const bool fused = [] { const char *e = getenv("GPCORE_GEMM_FUSED"); return !e || atoi(e) != 0; }();
-    if (fused && M >= FM) {
+    // 256-row tiles by ONE 8-wave workgroup per CU where they fit (8 waves x 64x64; 16 waves x 64x32 measured 0.6 % slower: a third more
+    // LDS fragment reads in a power-limited loop); an odd 128-row remainder goes through the 128-row kernel below
+    if (M >= FM) {
         // One workgroup per CU: a launch costs whole ROUNDS of num_cu tiles, whatever the last round holds.  Full rounds go to the
         // 256-row kernel; of what is left, up to num_cu 128-row tiles are cheaper on the 8-wave kernel below (one workgroup per CU on
         // half a tile's work: 0.55-0.6 of a round) than a 256-row round that is at most half full.  (Config C5: the last batch of a
@@ -780,33 +559,24 @@ void gpk_gemm_nt_rowred(hipStream_t s, int M, int N, int K, const double *A, int
         if (Mf == 0) goto small_tiles;
         gemm_rowred r2;
         r2.sumsq = sumsq, r2.tvec = tvec, r2.dots = dots;
-        static const bool w8 = [] { const char *e = getenv("GPCORE_FUSED_WAVES"); return !(e && atoi(e) == 16); }();   // 8 waves x 64x64 measured +0.6 % over 16 x 64x32 (a third fewer LDS fragment reads; the loop is power-limited)
-        if (w8)
-            hipLaunchKernelGGL((gemm_fused_kernel<0, 0, 1, 8>), dim3(Mf / FM), dim3(512), FUSED_LDS, s, Mf, TN, K, 1.0, A, lda, B, ldb, 0.0, C, ldc, gp_batch(), r2);
-        else
-            hipLaunchKernelGGL((gemm_fused_kernel<0, 0, 1>), dim3(Mf / FM), dim3(1024), FUSED_LDS, s, Mf, TN, K, 1.0, A, lda, B, ldb, 0.0, C, ldc, gp_batch(), r2);
+        hipLaunchKernelGGL((gemm_fused_kernel<0, 0, 1, 8>), dim3(Mf / FM), dim3(512), FUSED_LDS, s, Mf, TN, K, 1.0, A, lda, B, ldb, 0.0, C, ldc, gp_batch(), r2);
         if (Mf == M) return;
         A += Mf, C += Mf, sumsq += Mf, M -= Mf;
         if (dots) dots += Mf;
     }
 small_tiles:
-    static const int nw = [] { const char *e = getenv("GPCORE_GEMM_WAVES"); return (e && atoi(e) == 4) ? 4 : 8; }();
     gemm_rowred rr;
     rr.sumsq = sumsq, rr.tvec = tvec, rr.dots = dots;
     const int ntiles = (M / TM) * (N / TN);
-    if (nw == 8)
-        hipLaunchKernelGGL((gemm_nt_f64_kernel<0, 0, 8, 1>), dim3(ntiles), dim3(512), 0, s, M, N, K, 1.0, A, lda, B, ldb, 0.0, C, ldc, 0, gp_batch(), rr, nullptr, 0, nullptr);
-    else
-        hipLaunchKernelGGL((gemm_nt_f64_kernel<0, 0, 4, 1>), dim3(ntiles), dim3(256), 0, s, M, N, K, 1.0, A, lda, B, ldb, 0.0, C, ldc, 0, gp_batch(), rr, nullptr, 0, nullptr);
+    hipLaunchKernelGGL((gemm_nt_f64_kernel<0, 0, 8, 1>), dim3(ntiles), dim3(512), 0, s, M, N, K, 1.0, A, lda, B, ldb, 0.0, C, ldc, 0, gp_batch(), rr, nullptr, 0, nullptr);
 }
 
 // C (M x N, lower trapezoid if `lower`) -= A (M x 128) B (N x 128)^T; M, N multiples of 64
-void gpk_gemm_k128_sub(hipStream_t s, int M, int N, const double *A, int lda, const double *B, int ldb, double *C, int ldc, int lower, int K,
-                       int skip_rows) {
+void gpk_gemm_k128_sub(hipStream_t s, int M, int N, const double *A, int lda, const double *B, int ldb, double *C, int ldc, int lower, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return;
     const int tm = M / SK_T, tn = N / SK_T;
-    if (lower) hipLaunchKernelGGL(gemm_k128_kernel<1>, dim3(tn * tm - tn * (tn - 1) / 2), dim3(256), 0, s, M, N, K, A, lda, B, ldb, C, ldc, skip_rows);
-    else hipLaunchKernelGGL(gemm_k128_kernel<0>, dim3(tm * tn), dim3(256), 0, s, M, N, K, A, lda, B, ldb, C, ldc, skip_rows);
+    if (lower) hipLaunchKernelGGL(gemm_k128_kernel<1>, dim3(tn * tm - tn * (tn - 1) / 2), dim3(256), 0, s, M, N, K, A, lda, B, ldb, C, ldc);
+    else hipLaunchKernelGGL(gemm_k128_kernel<0>, dim3(tm * tn), dim3(256), 0, s, M, N, K, A, lda, B, ldb, C, ldc);
 }
 
 double gpk_probe_mfma(hipStream_t s, int num_cu, int waves_per_simd, double *clock_mhz, double *cycles_per_mfma) {

@@ -471,6 +471,34 @@ GramParams make_params(const double *theta, int d, double extra) {
 
 }  // namespace
 
+namespace {
+
+// Centre of the matrix-core forms' z = (x - c) / l: the CENTROID of the training points (round 4; rounds 1-3 took the first training
+// point).  Any centre is exact in exact arithmetic -- it only decides how large |z|^2 gets, i.e. the rounding of the exponent and
+// whether the scan sends the call to the per-pair kernel -- and the centroid halves the norms of data that is spread evenly: config
+// C3's short-length-scale settings (s = 0.5: |z|^2 up to 100 from a corner point, 50 from the middle) stay on the unit kernel.
+// One block per feature, fixed summation order (thread t takes rows t, t + 256, ...; LDS tree): the same X gives the same centre.
+__global__ __launch_bounds__(256) void centroid_kernel(const double *__restrict__ X, int n, int ldx, double *__restrict__ c) {
+    __shared__ double red[256];
+    const double *col = X + (size_t)blockIdx.x * ldx;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) acc += col[i];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) c[blockIdx.x] = red[0] / (double)n;
+}
+
+}  // namespace
+
+void gpk_centroid(hipStream_t s, const double *X, int n, int d, int ldx, double *c) {
+    if (n <= 0 || d <= 0) return;
+    hipLaunchKernelGGL(centroid_kernel, dim3(d), dim3(256), 0, s, X, n, ldx, c);
+}
+
 // Which form builds the Gram matrices: 2 = the unit kernel (whole exponent on the matrix cores, d <= 14: every BASELINE configuration),
 // 1 = the LDS-staged matrix-core form (any d; the default from d = 16, where it beats the per-pair form 1.95 vs 2.68 ms at d = 32),
 // 0 = the per-pair form in the reference's own operation order.  GPCORE_GRAM_MFMA=0 forces the per-pair form, =1 a matrix-core form
@@ -518,19 +546,22 @@ static void launch_unit(hipStream_t s, const double *Xr, int nr, int ldxr, const
 #undef GU_LAUNCH
 }
 
-void gpk_gram_sym(hipStream_t s, const double *X, int n, int d, int ldx, const double *theta, double *K, int ldk, int full, double extra_diag, int *far_flag) {
+void gpk_gram_sym(hipStream_t s, const double *X, int n, int d, int ldx, const double *theta, double *K, int ldk, int full, double extra_diag, int *far_flag,
+                  const double *center) {
+    const double *cen = center ? center : X;      // d doubles (gpk_centroid) or, without one, the first point
+    const int ldcen = center ? 1 : ldx;
     GramParams p = make_params(theta, d, extra_diag);
     int nb = (n + GT - 1) / GT;
     const int form = far_flag ? gram_form(d, p, ldk) : 0;
     if (form == 2) {
         const int epoch = next_epoch();
-        if (full) launch_unit<2>(s, X, n, ldx, X, n, ldx, d, p, X, ldx, K, ldk, far_flag, epoch);
-        else launch_unit<1>(s, X, n, ldx, X, n, ldx, d, p, X, ldx, K, ldk, far_flag, epoch);
+        if (full) launch_unit<2>(s, X, n, ldx, X, n, ldx, d, p, cen, ldcen, K, ldk, far_flag, epoch);
+        else launch_unit<1>(s, X, n, ldx, X, n, ldx, d, p, cen, ldcen, K, ldk, far_flag, epoch);
         hipLaunchKernelGGL(gram_rbf_kernel<true>, dim3(nb * (nb + 1) / 2), dim3(256), 0, s, X, n, ldx, X, n, ldx, d, p, K, ldk, full, nb, far_flag, epoch);
         return;
     }
     if (form == 1) {
-        hipLaunchKernelGGL(gram_mfma_kernel<true>, dim3(nb * (nb + 1) / 2), dim3(256), 0, s, X, n, ldx, X, n, ldx, d, p, X, ldx, K, ldk, full, nb);
+        hipLaunchKernelGGL(gram_mfma_kernel<true>, dim3(nb * (nb + 1) / 2), dim3(256), 0, s, X, n, ldx, X, n, ldx, d, p, cen, ldcen, K, ldk, full, nb);
         return;
     }
     hipLaunchKernelGGL(gram_rbf_kernel<true>, dim3(nb * (nb + 1) / 2), dim3(256), 0, s, X, n, ldx, X, n, ldx, d, p, K, ldk, full, nb);
@@ -546,18 +577,21 @@ void gpk_dgram_sym(hipStream_t s, const double *X, int n, int d, int ldx, const 
     hipLaunchKernelGGL((gram_rbf_kernel<true, true>), dim3(nb * (nb + 1) / 2), dim3(256), 0, s, X, n, ldx, X, n, ldx, d, p, D, ldd, 1, nb);
 }
 
-void gpk_gram_cross(hipStream_t s, const double *Xs, int m, int ldxs, const double *X, int n, int ldx, int d, const double *theta, double *Ks, int ldks, int *far_flag) {
+void gpk_gram_cross(hipStream_t s, const double *Xs, int m, int ldxs, const double *X, int n, int ldx, int d, const double *theta, double *Ks, int ldks, int *far_flag,
+                    const double *center) {
+    const double *cen = center ? center : X;      // the TRAINING points' centre for both operands
+    const int ldcen = center ? 1 : ldx;
     GramParams p = make_params(theta, d, 0.0);
     int nbr = (m + GT - 1) / GT, nbc = (n + GT - 1) / GT;
     const int form = far_flag ? gram_form(d, p, ldks) : 0;
-    if (form == 2) {          // centre = first TRAINING point for both operands
+    if (form == 2) {
         const int epoch = next_epoch();
-        launch_unit<0>(s, Xs, m, ldxs, X, n, ldx, d, p, X, ldx, Ks, ldks, far_flag, epoch);
+        launch_unit<0>(s, Xs, m, ldxs, X, n, ldx, d, p, cen, ldcen, Ks, ldks, far_flag, epoch);
         hipLaunchKernelGGL(gram_rbf_kernel<false>, dim3(nbr * nbc), dim3(256), 0, s, Xs, m, ldxs, X, n, ldx, d, p, Ks, ldks, 1, nbr, far_flag, epoch);
         return;
     }
     if (form == 1) {
-        hipLaunchKernelGGL(gram_mfma_kernel<false>, dim3(nbr * nbc), dim3(256), 0, s, Xs, m, ldxs, X, n, ldx, d, p, X, ldx, Ks, ldks, 1, nbr);
+        hipLaunchKernelGGL(gram_mfma_kernel<false>, dim3(nbr * nbc), dim3(256), 0, s, Xs, m, ldxs, X, n, ldx, d, p, cen, ldcen, Ks, ldks, 1, nbr);
         return;
     }
     hipLaunchKernelGGL(gram_rbf_kernel<false>, dim3(nbr * nbc), dim3(256), 0, s, Xs, m, ldxs, X, n, ldx, d, p, Ks, ldks, 1, nbr);

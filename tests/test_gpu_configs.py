@@ -212,33 +212,37 @@ def test_ep_streamed_refactorisation_at_a_ragged_size(ctx, monkeypatch):
     assert abs(g["lml"] - got["0"]["lml"]) <= 1e-9 * abs(got["0"]["lml"])
 
 
-@pytest.mark.parametrize("n", [300, 1100, 2500])
-def test_cholesky_fused_diagonal_chain_is_the_same_factorisation(ctx, monkeypatch, n):
-    """GPCORE_CHOL_FUSED = 1 (chol_fused: the link to the step before as the prologue of the diagonal-block kernel, the rest of the panel
-    on a helper stream released by a device flag; measured slower, off by default) against the three-launch chain: the link computes
-    block k's rows and diagonal tile with the kernels' own tile arithmetic in another order of summation -> equal to rounding; both
-    against the oracle's dpotf2.  n = 2500: five outer panels, a ragged last block; the failing pivot is found in both forms."""
+@pytest.mark.parametrize("n", [1100, 2500, 4000])
+def test_cholesky_lookahead_forms_agree_with_the_first_bad_pivot(ctx, n):
+    """The far trailing updates on the CU-masked side stream (look-ahead forced on) against the one-stream form at sizes with 3, 5 and 8
+    outer panels and a ragged last block: the same tiles by the same kernels, so the factor is IDENTICAL, and so is the first bad
+    pivot -- inside the first panel, inside a later panel, in the last block."""
     from gp_algos_amd import _lib as L
     p = synth.regression(n, 3, 0, 5, 6, 0, synth.ard_theta(3, 1.3, 0.9, 0.3))
     K = orc.gram_sym(p["X"], p["theta"])
-    got = {}
-    for f in ("1", "0"):
-        monkeypatch.setenv("GPCORE_CHOL_FUSED", f)
-        got[f] = ctx.potrf_lower(K.copy(order="F"))
-    Lo = orc.cholesky_lower(K) if n <= 1100 else None
-    assert np.max(np.abs(got["1"] - got["0"])) <= 1e-12 * np.max(np.abs(got["0"]))
-    assert np.all(np.triu(got["1"], 1) == 0.0)
-    assert np.linalg.norm(got["1"] @ got["1"].T - K) / np.linalg.norm(K) <= 1e-13
-    if Lo is not None:
-        assert np.max(np.abs(got["1"] - Lo)) <= 1e-10 * np.max(np.abs(Lo))
-    Kbad = K.copy(order="F")
-    j = n - 7
-    Kbad[j, j] = -1.0
-    for f in ("1", "0"):
-        monkeypatch.setenv("GPCORE_CHOL_FUSED", f)
-        with pytest.raises(L.NotPositiveDefinite) as ei:
-            ctx.potrf_lower(Kbad.copy(order="F"))
-        assert ei.value.info == j + 1
+    lib = ctx._lib
+    try:
+        ctx.check(lib.gp_ctx_set_lookahead(ctx.h, 1))
+        ahead = [ctx.potrf_lower(K.copy(order="F")) for _ in range(2)]
+        ctx.check(lib.gp_ctx_set_lookahead(ctx.h, 0))
+        one = ctx.potrf_lower(K.copy(order="F"))
+        for g in ahead:
+            assert np.array_equal(g, one)
+        assert np.all(np.triu(one, 1) == 0.0)
+        assert np.linalg.norm(one @ one.T - K) / np.linalg.norm(K) <= 1e-13
+        if n <= 1100:
+            Lo = orc.cholesky_lower(K)
+            assert np.max(np.abs(one - Lo)) <= 1e-10 * np.max(np.abs(Lo))
+        for j in (n - 7, 700, 130):
+            Kbad = K.copy(order="F")
+            Kbad[j, j] = -1.0
+            for la in (1, 0):
+                ctx.check(lib.gp_ctx_set_lookahead(ctx.h, la))
+                with pytest.raises(L.NotPositiveDefinite) as ei:
+                    ctx.potrf_lower(Kbad.copy(order="F"))
+                assert ei.value.info == j + 1
+    finally:
+        ctx.check(lib.gp_ctx_set_lookahead(ctx.h, -1))
 
 
 def test_cholesky_lookahead_on_the_side_stream_is_the_same_factorisation(ctx):
