@@ -185,9 +185,8 @@ void chol_blocked(gp_ctx *ctx, double *A, int np, int lda, double *dinv, int ext
             const int c2 = c1 + nnext;
             const double *P2 = A + (size_t)c2 + (size_t)K0 * lda;
             gp_prof_begin(ctx, GP_PROF_SYRK, s2);
-            static const bool far_small = [] { const char *e = getenv("GPCORE_FAR_SMALL"); return e && atoi(e) != 0; }();   // lab switch (round 4)
-            if (far_small) gpk_gemm_k128_sub(s2, rows - c2, np - c2, P2, lda, P2, lda, A + (size_t)c2 + (size_t)c2 * lda, lda, 1, wcols);
-            else
+            // (the far update on the 64 x 64-tile kernel, whose workgroups retire four times as often: n = 8192 refit 6.32 against 5.94 ms,
+            //  n = 12288 16.4 against 14.5; the main stream at the device's highest priority: 5.93 against 5.94 -- profiles/r04_c_fit_priority_far_small.log)
             gpk_gemm_nt(s2, rows - c2, np - c2, wcols, -1.0, P2, lda, P2, lda, 1.0, A + (size_t)c2 + (size_t)c2 * lda, lda, 1);
             gp_prof_end(ctx, GP_PROF_SYRK, trapezoid_flops(rows - c2, np - c2, wcols), s2);
             (void)hipEventRecord(ctx->ev_b, s2);
@@ -582,16 +581,7 @@ gp_status gp_ctx_create(int device, void *stream, gp_ctx **out) {
     }
     if (e == hipSuccess) {
         if (stream) { ctx->stream = static_cast<hipStream_t>(stream); ctx->own_stream = false; }
-        else {
-            // lab switch (round 4): the caller-facing stream at the highest priority the device offers, so that the chain's kernels go
-            // ahead of the helper streams' workgroups whenever a CU slot frees
-            const char *pe = getenv("GPCORE_MAIN_PRIORITY");
-            int lo = 0, hi = 0;
-            if (pe && atoi(pe) != 0 && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess)
-                e = hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, hi);
-            else e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
-            ctx->own_stream = true;
-        }
+        else { e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking); ctx->own_stream = true; }
     }
     if (e == hipSuccess) {
         // Side stream for the far trailing update of the Cholesky.  It is CU-masked to leave a few CUs free of its
@@ -763,8 +753,8 @@ gp_status gp_gram_rbf_dev(gp_ctx *ctx, const double *dX, int n, int d, int ldx, 
     GP_REQUIRE(ctx, n >= 0 && d >= 1 && d <= 64 && ldx >= n && ldk >= n, "bad dimensions (1 <= d <= 64)");
     if (n == 0) return GP_OK;
     gp_prof_begin(ctx, GP_PROF_GRAM);
-    gpk_centroid(ctx->stream, dX, n, d, ldx, gp_gram_center(ctx));
-    gpk_gram_sym(ctx->stream, dX, n, d, ldx, theta, dK, ldk, uplo == GP_FULL, 0.0, gp_gram_flag(ctx), gp_gram_center(ctx));
+    // (one-shot call: the first point as centre, no extra launch; a fitted model and the batched paths use the centroid, computed once)
+    gpk_gram_sym(ctx->stream, dX, n, d, ldx, theta, dK, ldk, uplo == GP_FULL, 0.0, gp_gram_flag(ctx));
     gp_prof_end(ctx, GP_PROF_GRAM, uplo == GP_FULL ? 8.0 * n * (double)n + 8.0 * n * d : 8.0 * n * (n + 1.0) / 2.0 + 8.0 * n * d);
     return GP_OK;
 }
@@ -813,8 +803,7 @@ gp_status gp_cross_gram_rbf(gp_ctx *ctx, const double *Xs, int m, int ldxs, cons
     GP_TRY(ws_get(ctx, WS_B, sizeof(double) * (size_t)m * n, &dK));
     GP_TRY(upload_2d(ctx, dXs, m, Xs, ldxs, m, d));
     GP_TRY(upload_2d(ctx, dX, n, X, ldx, n, d));
-    gpk_centroid(ctx->stream, dX, n, d, n, gp_gram_center(ctx));
-    gpk_gram_cross(ctx->stream, dXs, m, m, dX, n, n, d, theta, dK, m, gp_gram_flag(ctx), gp_gram_center(ctx));
+    gpk_gram_cross(ctx->stream, dXs, m, m, dX, n, n, d, theta, dK, m, gp_gram_flag(ctx));
     return download_2d(ctx, Ks, ldks, dK, m, m, n);
 }
 
@@ -1219,8 +1208,7 @@ extern "C" gp_status gp_posterior_from_factor(gp_ctx *ctx, const double *X, int 
     GP_TRY(upload_2d(ctx, dX, n, X, ldx, n, d));
     GP_HIP(ctx, hipMemsetAsync(Vt, 0, sizeof(double) * (size_t)mp * np, s));
     gp_prof_begin(ctx, GP_PROF_GRAM);
-    gpk_centroid(s, dX, n, d, n, gp_gram_center(ctx));
-    gpk_gram_cross(s, dXs, m, m, dX, n, n, d, theta, Vt, mp, gp_gram_flag(ctx), gp_gram_center(ctx));
+    gpk_gram_cross(s, dXs, m, m, dX, n, n, d, theta, Vt, mp, gp_gram_flag(ctx));
     gp_prof_end(ctx, GP_PROF_GRAM, 8.0 * m * (double)n + 8.0 * (m + n) * d);
     GP_TRY(posterior_rows(ctx, Vt, m, mp, f, dout, dout + mp));
     GP_TRY(download_2d(ctx, mean, m, dout, m, m, 1));

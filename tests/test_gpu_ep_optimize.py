@@ -9,6 +9,7 @@ from gp_algos_amd import synth
 from oracle import gp_oracle as orc
 
 pytestmark = pytest.mark.gpu
+TOL_GRAD = 1e-8      # gradient, relative to max |grad| (measured against the oracle: <= 6e-15, profiles/r04_c_ep_grad_errors.log)
 
 
 @pytest.fixture(scope="module")
@@ -39,7 +40,7 @@ def test_ep_lml_and_gradient_over_settings_vs_oracle(ctx, strict):
         ol = orc.ep_lml(o, y, strict)
         og = orc.ep_lml_grad(p["X"], thetas[b], K, o["L"], o["tau"], o["nu"], strict=strict)
         assert abs(lml[b] - ol) <= 1e-8 * abs(ol), b
-        assert np.max(np.abs(grad[b] - og)) <= 1e-6 * np.max(np.abs(og)), b
+        assert np.max(np.abs(grad[b] - og)) <= TOL_GRAD * np.max(np.abs(og)), b
     # the LML-only entry gives the same values; fixed sweep counts too
     l2, s2, _ = ctx.ep_lml_rbf_batched(p["X"], y, thetas, stop_eps=0.01, max_sweeps=30, strict=strict)
     assert np.array_equal(l2, lml) and np.array_equal(s2, sweeps)
@@ -132,7 +133,7 @@ def test_ep_lockstep_batch_vs_oracle_small(ctx, monkeypatch, strict):
         ol = orc.ep_lml(o, y, strict)
         og = orc.ep_lml_grad(p["X"], thetas[b], K, o["L"], o["tau"], o["nu"], strict=strict)
         assert abs(lml[b] - ol) <= 1e-8 * abs(ol), b
-        assert np.max(np.abs(grad[b] - og)) <= 1e-6 * np.max(np.abs(og)), b
+        assert np.max(np.abs(grad[b] - og)) <= TOL_GRAD * np.max(np.abs(og)), b
     # one setting at a time (the path it replaces) in the same form of the sweep -- refactorisation streamed under the site loop, fused
     # chain kernel; at this size a single run would default to the end-of-sweep form, whose scaling rounds elsewhere: the same bits
     monkeypatch.setenv("GPCORE_EP_LOCKSTEP", "0")
@@ -158,16 +159,19 @@ def test_ep_lockstep_batch_at_size_vs_oracle_and_serial(ctx, monkeypatch):
         ol = orc.ep_lml(o, y, False)
         og = orc.ep_lml_grad(p["X"], thetas[b], K, o["L"], o["tau"], o["nu"], strict=False)
         assert abs(lml[b] - ol) <= 1e-8 * abs(ol), b
-        assert np.max(np.abs(grad[b] - og)) <= 1e-6 * np.max(np.abs(og)), b
+        assert np.max(np.abs(grad[b] - og)) <= TOL_GRAD * np.max(np.abs(og)), b
     lc, gc, sc, ic = ctx.ep_lml_grad_rbf_batched(p["X"], y, thetas, stop_eps=0.01, max_sweeps=40, strict=False)
     monkeypatch.setenv("GPCORE_EP_LOCKSTEP", "0")
     l1, g1, s1, i1 = ctx.ep_lml_grad_rbf_batched(p["X"], y, thetas, stop_eps=0.01, max_sweeps=40, strict=False)
     assert np.array_equal(sc, s1) and np.array_equal(lc, l1) and np.array_equal(gc, g1) and np.all(ic == 0)
 
 
-def test_ep_lockstep_batch_with_a_failing_member(ctx, monkeypatch):
-    """A setting whose EP run breaks down (negative site precisions -> I + S^1/2 K S^1/2 not PD) leaves the batch with NaN results and its
-    failing pivot; the others are unaffected (same bits as without it)."""
+def test_ep_lockstep_batch_with_an_extreme_member(ctx, monkeypatch):
+    """An absurd signal variance (sf = 1e8) among ordinary settings.  ONE outcome, the reference's: the literal loop of
+    EpParameterEstimator.scala:40-62 stays finite on it (site precisions ~1e-19, the criterion of :187-202 holds after one sweep), so
+    the device reports info = 0, the same sweep count and the same LML; the other members are unaffected (same bits as without it).
+    (Rounds 2-3 accepted "a failure or not" here.)  The break-down path itself -- a negative site precision, the first bad pivot --
+    is pinned on ready-made matrices in tests/test_gpu_ep_edge_cases.py."""
     monkeypatch.setenv("GPCORE_EP_LOCKSTEP", "1")
     monkeypatch.setenv("GPCORE_EP_GROUP", "3")
     p, y = _ep_problem(260, seed=51)
@@ -175,10 +179,15 @@ def test_ep_lockstep_batch_with_a_failing_member(ctx, monkeypatch):
     l0, g0, s0, i0 = ctx.ep_lml_grad_rbf_batched(p["X"], y, good, stop_eps=0.01, max_sweeps=25, strict=False)
     assert np.all(i0 == 0)
     bad = p["theta"].copy()
-    bad[0] = 1e8                                           # an absurd signal variance: the site updates overflow into NaN
+    bad[0] = 1e8
     thetas = np.vstack([good[:1], bad[None, :], good[1:]])
     l1, g1, s1, i1 = ctx.ep_lml_grad_rbf_batched(p["X"], y, thetas, stop_eps=0.01, max_sweeps=25, strict=False)
     keep = [0, 2, 3]
     assert np.array_equal(l1[keep], l0) and np.array_equal(g1[keep], g0) and np.array_equal(s1[keep], s0)
-    if i1[1] != 0:
-        assert np.isnan(l1[1]) and np.all(np.isnan(g1[1]))
+    Kb = orc.gram_sym(p["X"], bad)
+    o = orc.ep_estimate(Kb, y, 25, eps=0.01)
+    assert i1[1] == 0 and s1[1] == o["sweeps"] == 1
+    ol = orc.ep_lml(o, y, False)
+    assert abs(l1[1] - ol) <= 1e-8 * abs(ol)
+    og = orc.ep_lml_grad(p["X"], bad, Kb, o["L"], o["tau"], o["nu"], strict=False)
+    assert np.all(np.isfinite(g1[1])) and np.max(np.abs(g1[1] - og)) <= TOL_GRAD * np.max(np.abs(og))

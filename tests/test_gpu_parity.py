@@ -75,12 +75,12 @@ def test_gram_forms_matrix_core_and_per_pair(ctx, monkeypatch, force, n, d, m):
 @pytest.mark.parametrize("n,d,m,scale", [(257, 8, 130, 0.2), (200, 3, 70, 0.08), (330, 14, 65, 0.3), (130, 1, 64, 0.01)])
 def test_gram_points_far_from_the_centre_take_the_per_pair_path(ctx, monkeypatch, n, d, m, scale):
     """The default builder for d <= 14 has the exponent on the matrix cores as ln sf^2 - |z_i|^2/2 - |z_j|^2/2 + z_i.z_j, whose absolute
-    error grows with |z|^2 (z = (x - c) / l, c the centroid of the training points): a scan in front of it looks for a point with
-    |z|^2 > 64, and if there is one the per-pair kernel launched behind it (the reference's own order) builds the matrix instead.
-    Short length scales do that."""
+    error grows with |z|^2 (z = (x - c) / l; c = the first training point in these one-shot calls, the centroid of the training points
+    for a fitted model and the batched paths): a scan in front of it looks for a point with |z|^2 > 64, and if there is one the
+    per-pair kernel launched behind it (the reference's own order) builds the matrix instead.  Short length scales do that."""
     p = _problem(n, d, m, seed=7 * n + d, scale=scale)
-    z2 = (((p["X"] - p["X"].mean(axis=0)) / p["theta"][1:d + 1]) ** 2).sum(axis=1)
-    assert z2.max() > 64.0
+    for c in (p["X"][0], p["X"].mean(axis=0)):
+        assert ((((p["X"] - c) / p["theta"][1:d + 1]) ** 2).sum(axis=1)).max() > 64.0
     Ko = orc.gram_sym(p["X"], p["theta"])
 
     def close(K, Ko, sel):
@@ -107,6 +107,31 @@ def test_gram_points_far_from_the_centre_take_the_per_pair_path(ctx, monkeypatch
     K = ctx.gram_rbf(p["X"], p["theta"])
     monkeypatch.setenv("GPCORE_GRAM_MFMA", "0")
     assert np.array_equal(K, ctx.gram_rbf(p["X"], p["theta"])) and np.array_equal(Ks, ctx.cross_gram_rbf(p["Xs"], p["X"], p["theta"]))
+
+
+def test_gram_centroid_keeps_evenly_spread_data_on_the_matrix_core_kernel(ctx, monkeypatch):
+    """Round 4: a fitted model and the batched LML path take z against the CENTROID of the training points.  Config C3's
+    short-length-scale settings (s = 0.5 on X uniform in [-2, 2]^8) have |z|^2 up to ~100 from a corner point but < 64 from the
+    middle: they now stay on the unit kernel (different bits from the per-pair kernel, same 1e-11 on the LML; gradient at the
+    tolerance BASELINE.md states), where rounds 1-3 sent them to the per-pair kernel."""
+    n, d = 700, 8
+    p = synth.config_c3(n, d)
+    th = [t for t in p["thetas"] if abs(t[1] - 0.5) < 1e-12][:3]          # l_1 = s = 0.5
+    assert len(th) == 3
+    X = p["X"]
+    z2c = (((X - X.mean(axis=0)) / th[0][1:d + 1]) ** 2).sum(axis=1).max()
+    z20 = (((X - X[0]) / th[0][1:d + 1]) ** 2).sum(axis=1).max()
+    assert z2c < 64.0 < z20
+    l1, g1, i1 = ctx.lml_grad_batched(X, p["y"], np.array(th))
+    monkeypatch.setenv("GPCORE_GRAM_MFMA", "0")
+    l0, g0, i0 = ctx.lml_grad_batched(X, p["y"], np.array(th))
+    assert np.all(i1 == 0) and np.all(i0 == 0)
+    assert not np.array_equal(l1, l0)                                      # the matrix-core kernel built these Gram matrices
+    assert np.max(np.abs(l1 - l0) / np.abs(l0)) <= 1e-11
+    assert np.max(np.abs(g1 - g0)) <= 1e-8 * np.max(np.abs(g0))
+    for b in range(3):
+        ol, og = orc.lml_grad(X, p["y"], th[b])
+        assert abs(l1[b] - ol) <= 1e-11 * abs(ol) and np.max(np.abs(g1[b] - og)) <= 1e-8 * np.max(np.abs(og))
 
 
 def test_gram_a_few_outliers_switch_the_whole_matrix(ctx, monkeypatch):
@@ -529,7 +554,7 @@ def test_ep_lml_gradient_vs_oracle(ctx, strict):   # MarginalLikelihoodEvaluator
     o = orc.ep_estimate(K, y, 3)
     og = orc.ep_lml_grad(p["X"], p["theta"], K, o["L"], o["tau"], o["nu"], strict=strict)
     assert g.shape == og.shape == (5,)
-    assert np.max(np.abs(g - og)) <= 1e-7 * np.max(np.abs(og))
+    assert np.max(np.abs(g - og)) <= TOL_GRAD * np.max(np.abs(og))       # measured <= 6e-15 (profiles/r04_c_ep_grad_errors.log)
     ep.close()
 
 
@@ -547,7 +572,7 @@ def test_marginal_likelihood_evaluator_mirror(ctx):
     o = orc.ep_estimate(K, y, 3)
     assert abs(lml - orc.ep_lml(o, y, True)) <= 1e-9 * abs(lml)
     og = orc.ep_lml_grad(p["X"], p["theta"], K, o["L"], o["tau"], o["nu"], strict=True)
-    assert np.max(np.abs(grad - og)) <= 1e-7 * np.max(np.abs(og))
+    assert np.max(np.abs(grad - og)) <= TOL_GRAD * np.max(np.abs(og))
     ev2 = MarginalLikelihoodEvaluator(FixedSweepsStopCriterion(3), kf, strict=True)
     mesh = MeshHyperParamsLogLikelihoodEvaluator(MarginalLikelihoodEvaluator(FixedSweepsStopCriterion(2), kf))
     settings, vals = mesh.evaluate([[1.0, 1.5], [1.0], [1.2], [0.9, 1.4], [0.0]], p["X"], y)
