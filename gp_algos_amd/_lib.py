@@ -33,6 +33,7 @@ SIGNATURES = {
     "gp_ctx_profile": (_i, [_vp, _i]),
     "gp_ctx_set_lookahead": (_i, [_vp, _i]),
     "gp_ctx_profile_read": (_i, [_vp, _i, C.POINTER(C.c_int64), _dp, _dp]),
+    "gp_chol_plan_info": (_i, [_i, _i, _i, _ip, _dp]),
     "gp_probe_mfma_f64": (_i, [_vp, _dp]),
     "gp_probe_mfma_f64_ex": (_i, [_vp, _i, _dp, _dp, _dp]),
     "gp_dev_alloc": (_i, [_vp, _sz, C.POINTER(_vp)]),

@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <queue>
 #include <functional>
 #include <new>
 #include <thread>
@@ -33,7 +34,12 @@ namespace {
 // tag: what a caller that wants to find its own invariants again next time wrote there (0 = nothing promised; ws_get resets it)
 struct ws_slot { void *p = nullptr; size_t bytes = 0; unsigned long long tag = 0; };
 
-struct ctx_ext { ws_slot ws[WS_COUNT]; std::vector<gp_ctx *> children; };
+struct mega_task { int type, k0, kb, i, j, q, dep[10]; };
+struct mega_plan { int np = 0, extra = 0, out_blocks = 0, workers = 0; double model_us = 0.0; std::vector<mega_task> tasks; };
+// the persistent-launch factorisation's state: the plan of the shape used last, its copy on the device, the flags
+struct mega_state { mega_plan plan; int *d_tasks = nullptr, *d_done = nullptr, *d_ctl = nullptr; int cap = 0, epoch = 0; };
+
+struct ctx_ext { ws_slot ws[WS_COUNT]; std::vector<gp_ctx *> children; mega_state mega; };
 
 // gp_ctx owns a ctx_ext through this side table (keeps the header struct POD-ish)
 ctx_ext *ext_of(gp_ctx *ctx);
@@ -85,9 +91,17 @@ gp_status download_2d(gp_ctx *ctx, double *dst, int ldd, const double *src, int 
 }
 
 gp_status read_info(gp_ctx *ctx, int *info) {
-    int h = 0;
+    int h = 0, merr = 0;
     GP_HIP(ctx, hipMemcpyAsync(&h, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    mega_state &ms = ext_of(ctx)->mega;
+    if (ms.d_ctl) GP_HIP(ctx, hipMemcpyAsync(&merr, ms.d_ctl + 1, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     GP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (merr != 0) {   // a workgroup of chol_mega_kernel gave up waiting for a task it depends on: never expected, reported rather than hung
+        (void)hipMemsetAsync(ms.d_ctl + 1, 0, sizeof(int), ctx->stream);
+        if (info) *info = 0;
+        GP_SET_ERR(ctx, "Cholesky (single launch): task %d waited for a dependency beyond its bound", merr - 1);
+        return GP_EHIP;
+    }
     if (info) *info = h;
     return GP_OK;
 }
@@ -124,6 +138,212 @@ void gemm_sub_single(hipStream_t s, int M, int N, int K, const double *A, int ld
 //       stream, under the next panel's chain of single-workgroup kernels (which need a whole CU's LDS: the mask keeps CUs free).
 // `extra` (0 or GP_NB) rows below the matrix ride along: with y^T in row np this leaves (L^-1 y)^T there.
 // count > 1: a lockstep batch -- problem g lives at A + g*strideA, dinv + g*strideDinv, info + g; every launch covers all of them.
+// ---- the factorisation of ONE matrix as one persistent launch (chol_mega_kernel, kernels_diag.hip) ----
+// Task list of the two-level right-looking factorisation (inner 128, outer panels of `out_blocks` block columns), in a LIST-SCHEDULE
+// order: the tasks are generated in the order chol_blocked launches them, a critical-path-first schedule of that DAG on `workers`
+// workgroups is simulated with a cost model (us per task on one CU, measured with tools/mega_trace.py: diagonal block 25, 128-row panel
+// solve 22, 128 x 128 tile with K = 128 / 512: 28 / 81, a 64 x 64 quarter 9 / 20, a hand-over between workgroups 3), and the list is the tasks in the
+// order the simulation starts them.  Workgroups claim tasks in list order, so on the chip the dependencies of a claimed task are
+// mostly met already and the chain (diagonal block with its link to the block before; at a panel boundary: solve of the next block's rows -> the quarters of the next diagonal tile) is
+// never waiting behind throughput work.  Every dependency points BACKWARDS in the list (checked): no deadlock.
+bool chol_mega_plan(int np, int extra, int out_blocks, int workers, mega_plan &plan) {
+    const int nb = np / GP_NB, nrow = (np + extra) / GP_NB;
+    struct node { mega_task t; double cost; std::vector<int> deps; };
+    std::vector<node> g;
+    g.reserve((size_t)nb * nb);
+    std::vector<int> trsm_of((size_t)nb * nrow, -1), potrf_of(nb, -1);
+    // last writers of a tile: the task(s) whose result the next reader / writer of tile (i, j) must wait for (up to 4 quarters)
+    std::vector<std::vector<int>> last((size_t)nrow * nb);
+    auto tile = [&](int i, int j) -> std::vector<int> & { return last[(size_t)i * nb + j]; };
+    // us per task on one CU, from tools/mega_trace.py (profiles/r04_g_mega_trace.log): body + publish
+    const double c_potrf = 25.3, c_trsm = 21.7, c_k128 = 28.4, c_k512 = 81.0, c_q128 = 9.0, c_q512 = 30.0, c_link = 20.0;
+    auto add = [&](int type, int k0, int kb, int i, int j, int q, double cost, std::vector<int> deps) {
+        node nd;
+        nd.t = mega_task{type, k0, kb, i, j, q, {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1}};
+        nd.cost = cost;
+        std::sort(deps.begin(), deps.end());
+        deps.erase(std::unique(deps.begin(), deps.end()), deps.end());
+        nd.deps = deps;
+        g.push_back(nd);
+        return (int)g.size() - 1;
+    };
+    std::vector<int> pre_x;       // writers of tile (k+1, k) before its rows are solved: what the fused task of block k+1 waits for
+    for (int c0 = 0; c0 < nb; c0 += out_blocks) {
+        const int c1 = std::min(nb, c0 + out_blocks);
+        for (int k = c0; k < c1; ++k) {
+            if (k == c0) potrf_of[k] = add(0, k, 1, k, k, -1, c_potrf, tile(k, k));
+            else {
+                // inside the panel: the link to block k-1 (solve of rows k of block column k-1, last in-panel update of tile (k, k)) is the
+                // prologue of the diagonal block's task; the place holder made in step k-1 stands for the solved rows
+                std::vector<int> d = tile(k, k);
+                d.insert(d.end(), pre_x.begin(), pre_x.end());
+                d.push_back(potrf_of[k - 1]);
+                potrf_of[k] = add(4, k, 1, k, k, trsm_of[(size_t)(k - 1) * nrow + k], c_link + c_potrf, d);
+                g[trsm_of[(size_t)(k - 1) * nrow + k]].t.kb = potrf_of[k];      // the place holder remembers who announces it
+            }
+            tile(k, k) = {potrf_of[k]};
+            for (int i = k + 1; i < nrow; ++i) {
+                if (i == k + 1 && i < c1) {
+                    pre_x = tile(i, k);
+                    trsm_of[(size_t)k * nrow + i] = add(3, k, -1, i, k, -1, -1.0, {});
+                    tile(i, k) = {trsm_of[(size_t)k * nrow + i]};
+                    continue;
+                }
+                std::vector<int> d = tile(i, k);
+                d.push_back(potrf_of[k]);
+                trsm_of[(size_t)k * nrow + i] = add(1, k, 1, i, k, -1, c_trsm, d);
+                tile(i, k) = {trsm_of[(size_t)k * nrow + i]};
+            }
+            for (int j = k + 1; j < c1; ++j)
+                for (int i = j; i < nrow; ++i) {
+                    if (i == k + 1 && j == k + 1) continue;      // the next diagonal tile's update is part of that block's fused task
+                    std::vector<int> d = tile(i, j);
+                    d.push_back(trsm_of[(size_t)k * nrow + i]);
+                    d.push_back(trsm_of[(size_t)k * nrow + j]);
+                    tile(i, j) = {add(2, k, 1, i, j, -1, c_k128, d)};
+                }
+        }
+        for (int j = c1; j < nb; ++j)
+            for (int i = j; i < nrow; ++i) {
+                std::vector<int> d = tile(i, j);
+                d.push_back(trsm_of[(size_t)(c1 - 1) * nrow + i]);      // block column c1-1 of row block i is the last of the panel to be solved
+                d.push_back(trsm_of[(size_t)(c1 - 1) * nrow + j]);
+                const int kb = c1 - c0;
+                const double cost = c_k128 + (c_k512 - c_k128) * (kb - 1) / 3.0, qcost = c_q128 + (c_q512 - c_q128) * (kb - 1) / 3.0;
+                if (i < c1 + out_blocks && j < c1 + out_blocks && i < nb) {      // the next outer panel's diagonal block: quarters
+                    std::vector<int> w;
+                    for (int q = 0; q < 4; ++q)
+                        if (!(i == j && q == 2)) w.push_back(add(2, c0, kb, i, j, q, qcost, d));   // q = (row half) + 2 (column half); (0, 1) is above the diagonal
+                    tile(i, j) = w;
+                } else tile(i, j) = {add(2, c0, kb, i, j, -1, cost, d)};
+            }
+    }
+    const int n = (int)g.size();
+    for (const node &nd : g) if (nd.deps.size() > 10) return false;
+    // critical-path priorities and the simulated list schedule
+    const double hop = 3.0;
+    std::vector<std::vector<int>> succ(n);
+    std::vector<int> indeg(n, 0);
+    for (int t = 0; t < n; ++t) { indeg[t] = (int)g[t].deps.size(); for (int d : g[t].deps) succ[d].push_back(t); }
+    std::vector<double> prio(n, 0.0), est(n, 0.0), start(n, 0.0);
+    for (int pass = 0; pass < 2; ++pass)      // twice: a fused task inherits the urgency of what waits for the rows it announces half-way
+        for (int t = n - 1; t >= 0; --t) {
+            double m = 0.0;
+            for (int s2 : succ[t]) m = std::max(m, prio[s2]);
+            prio[t] = std::max(g[t].cost, 0.0) + hop + m;
+            if (g[t].t.type == 4) prio[t] = std::max(prio[t], c_link + hop + prio[g[t].t.q]);
+        }
+    typedef std::pair<double, int> pdi;
+    std::priority_queue<pdi> ready;                                               // (priority, task): dependencies done
+    std::priority_queue<pdi, std::vector<pdi>, std::greater<pdi>> waiting;        // (earliest start, task): done, but the hand-over is still in flight
+    std::priority_queue<pdi, std::vector<pdi>, std::greater<pdi>> running;        // (finish time, task)
+    for (int t = 0; t < n; ++t) if (indeg[t] == 0 && g[t].t.type != 3) ready.push(pdi(prio[t], t));
+    int freew = workers, finished = 0;
+    double now = 0.0;
+    while (finished < n) {
+        while (!waiting.empty() && waiting.top().first <= now + 1e-9) { const int t = waiting.top().second; waiting.pop(); ready.push(pdi(prio[t], t)); }
+        while (freew > 0 && !ready.empty()) {
+            const int t = ready.top().second;
+            ready.pop();
+            start[t] = now;
+            running.push(pdi(now + g[t].cost, t));
+            --freew;
+            if (g[t].t.type == 4) {      // its place holder: announced c_link into the task, costs nobody a workgroup
+                const int ph = g[t].t.q;
+                start[ph] = now + 1e-3;
+                running.push(pdi(now + c_link, ph));
+            }
+        }
+        double next = running.empty() ? 1e300 : running.top().first;
+        if (freew > 0 && !waiting.empty()) next = std::min(next, waiting.top().first);
+        if (next >= 1e300) return false;      // not reached for a valid DAG
+        now = next;
+        while (!running.empty() && running.top().first <= now + 1e-9) {
+            const int t = running.top().second;
+            running.pop();
+            ++finished;
+            if (g[t].t.type != 3) ++freew;
+            for (int s2 : succ[t]) {
+                est[s2] = std::max(est[s2], now + hop);
+                if (--indeg[s2] == 0) waiting.push(pdi(est[s2], s2));
+            }
+        }
+    }
+    std::vector<int> order(n), pos(n);
+    for (int t = 0; t < n; ++t) order[t] = t;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return start[a] < start[b] || (start[a] == start[b] && prio[a] > prio[b]); });
+    for (int p2 = 0; p2 < n; ++p2) pos[order[p2]] = p2;
+    plan.tasks.resize(n);
+    for (int p2 = 0; p2 < n; ++p2) {
+        const node &nd = g[order[p2]];
+        mega_task t = nd.t;
+        for (size_t d = 0; d < nd.deps.size(); ++d) {
+            t.dep[d] = pos[nd.deps[d]];
+            if (t.dep[d] >= p2) return false;      // a dependency that does not point backwards: never for a schedule (a task starts after its dependencies end)
+        }
+        if (t.type == 4) t.q = pos[t.q];           // the place holder it announces, by its place in the list
+        if (t.type == 3) t.kb = pos[t.kb];
+        plan.tasks[p2] = t;
+    }
+    plan.np = np, plan.extra = extra, plan.out_blocks = out_blocks, plan.workers = workers, plan.model_us = now;
+    return true;
+}
+
+// Runs the factorisation as one persistent launch on the context's stream; false = not available (allocation, planning): the caller
+// falls back to the launch-per-step form.  d_ctl: [0] the claim counter (zeroed in stream order before every launch), [1] the error word.
+bool chol_mega_run(gp_ctx *ctx, double *A, int np, int lda, double *dinv, int extra, int out_blocks) {
+    mega_state &ms = ext_of(ctx)->mega;
+    const int workers = ctx->num_cu;
+    if (ms.plan.np != np || ms.plan.extra != extra || ms.plan.out_blocks != out_blocks || ms.plan.workers != workers) {
+        mega_plan pl;
+        if (!chol_mega_plan(np, extra, out_blocks, workers, pl)) return false;
+        const int n = (int)pl.tasks.size();
+        if (n > ms.cap) {
+            if (hipStreamSynchronize(ctx->stream) != hipSuccess) return false;
+            if (ms.d_tasks) (void)hipFree(ms.d_tasks);
+            if (ms.d_done) (void)hipFree(ms.d_done);
+            ms.d_tasks = ms.d_done = nullptr, ms.cap = 0;
+            if (hipMalloc(&ms.d_tasks, sizeof(mega_task) * (size_t)n) != hipSuccess || hipMalloc(&ms.d_done, sizeof(int) * (size_t)n) != hipSuccess) {
+                (void)hipGetLastError();
+                return false;
+            }
+            if (hipMemset(ms.d_done, 0, sizeof(int) * (size_t)n) != hipSuccess) return false;
+            ms.cap = n;
+        }
+        if (!ms.d_ctl && (hipMalloc(&ms.d_ctl, sizeof(int) * 4) != hipSuccess || hipMemset(ms.d_ctl, 0, sizeof(int) * 4) != hipSuccess)) { (void)hipGetLastError(); return false; }
+        // (synchronous copy: the previous launch may still be reading the old list)
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) return false;
+        if (hipMemcpy(ms.d_tasks, pl.tasks.data(), sizeof(mega_task) * (size_t)n, hipMemcpyHostToDevice) != hipSuccess) return false;
+        ms.plan = std::move(pl);
+    }
+    const int n = (int)ms.plan.tasks.size();
+    if (++ms.epoch <= 0) { ms.epoch = 1; (void)hipMemsetAsync(ms.d_done, 0, sizeof(int) * (size_t)ms.cap, ctx->stream); }
+    (void)hipMemsetAsync(ms.d_ctl, 0, sizeof(int), ctx->stream);
+    // lab: GPCORE_MEGA_TRACE=<file> -- per-task time stamps (claimed / dependencies met / body done / published, 100 MHz ticks) and the
+    // task list of THIS launch written to <file> (tools/mega_trace.py reads it); synchronises, so never set it for a measurement
+    const char *trace = getenv("GPCORE_MEGA_TRACE");
+    unsigned long long *d_st = nullptr;
+    if (trace && hipMalloc(&d_st, sizeof(unsigned long long) * 4 * (size_t)n) != hipSuccess) { (void)hipGetLastError(); d_st = nullptr; }
+    if (d_st) (void)hipMemsetAsync(d_st, 0, sizeof(unsigned long long) * 4 * (size_t)n, ctx->stream);
+    gp_prof_begin(ctx, GP_PROF_SYRK);
+    gpk_chol_mega(ctx->stream, workers, A, lda, dinv, ctx->d_info, ms.d_tasks, n, ms.d_done, ms.d_ctl, ms.epoch, ms.d_ctl + 1, d_st);
+    gp_prof_end(ctx, GP_PROF_SYRK, (double)np * np * np / 3.0);
+    if (d_st) {
+        std::vector<unsigned long long> h(4 * (size_t)n);
+        if (hipStreamSynchronize(ctx->stream) == hipSuccess && hipMemcpy(h.data(), d_st, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost) == hipSuccess) {
+            if (FILE *f = fopen(trace, "wb")) {
+                const int hdr[4] = {n, np, extra, out_blocks};
+                fwrite(hdr, sizeof(int), 4, f);
+                fwrite(ms.plan.tasks.data(), sizeof(mega_task), (size_t)n, f);
+                fwrite(h.data(), sizeof(unsigned long long), h.size(), f);
+                fclose(f);
+            }
+        }
+        (void)hipFree(d_st);
+    }
+    return true;
+}
+
 void chol_blocked(gp_ctx *ctx, double *A, int np, int lda, double *dinv, int extra, int count = 1, size_t strideA = 0, size_t strideDinv = 0,
                   int *info = nullptr) {
     hipStream_t s = ctx->stream, s2 = ctx->side;
@@ -144,6 +364,18 @@ void chol_blocked(gp_ctx *ctx, double *A, int np, int lda, double *dinv, int ext
     // outer panel width: 512 (K = 512 trailing updates); 1024 measured 3 % faster at n = 32768 (205 -> 198.5 ms), equal at 8192
     const int outer_env = gp_env_blocks("GPCORE_OUTER");
     const int OUTER = outer_env ? outer_env : (np > 16384 ? 2 * GP_OUTER : GP_OUTER);
+    {   // One persistent launch instead of ~250 (chol_mega_kernel): single factorisations that would run with look-ahead, where it wins --
+        // refit ms, launch-per-step / single launch (profiles/r04_h_fit_mega.log): n = 4096 1.97 / 2.05, 5120 2.73 / 2.74, 6144 3.58 / 3.28,
+        // 7168 4.60 / 3.94, 8192 5.94 / 4.94, 10240 9.49 / 8.40, 12288 14.49 / 13.85, 14336 21.39 / 21.24, 16384 30.43 / 31.09: below ~5600
+        // rows the chain is the same length either way, above ~14000 the factorisation is bound by GEMM throughput and one workgroup per CU
+        // on 128 x 128 tiles (78 us per K = 512 tile) is no faster than two.  GPCORE_CHOL_MEGA = 0 / 1 forces (read per call: the tests
+        // run every form in one process).
+        const char *me = getenv("GPCORE_CHOL_MEGA");
+        const bool forced = me && atoi(me) != 0, off = me && atoi(me) == 0;
+        const bool by_size = np >= 5632 && np <= 14336;
+        if (!off && (forced || by_size) && lookahead && info == ctx->d_info && np >= 4 * OUTER && extra <= GP_NB &&
+            chol_mega_run(ctx, A, np, lda, dinv, extra, OUTER / GP_NB)) return;
+    }
     // (Round 4 tried the chain on the outer panel's OWN rows only, with the rows under the panel -- panel solve and their share of the
     // in-panel update -- on a second stream gated by one event per step: bit-identical, and slower at every size (n = 8192 refit 6.86
     // against 5.93 ms, profiles/r04_b_chol_split_fit.log).  Those launches are throughput work the step has to do anyway; moved off
@@ -631,6 +863,9 @@ void gp_ctx_destroy(gp_ctx *ctx) {
     x->children.clear();
     (void)hipSetDevice(ctx->device);
     for (int i = 0; i < WS_COUNT; ++i) if (x->ws[i].p) (void)hipFree(x->ws[i].p);
+    if (x->mega.d_tasks) (void)hipFree(x->mega.d_tasks);
+    if (x->mega.d_done) (void)hipFree(x->mega.d_done);
+    if (x->mega.d_ctl) (void)hipFree(x->mega.d_ctl);
     if (ctx->d_scalars) (void)hipFree(ctx->d_scalars);
     if (ctx->d_info) (void)hipFree(ctx->d_info);
     if (ctx->ev_a) (void)hipEventDestroy(ctx->ev_a);
@@ -698,6 +933,42 @@ gp_status gp_probe_mfma_f64(gp_ctx *ctx, double *tflops) {
     double v = gpk_probe_mfma(ctx->stream, ctx->num_cu, 2, nullptr, nullptr);
     if (v < 0) { GP_SET_ERR(ctx, "probe allocation failed"); return GP_ENOMEM; }
     *tflops = v;
+    return GP_OK;
+}
+
+gp_status gp_chol_plan_info(int n, int extra_rows, int workgroups, int *ntasks, double *model_us) {
+    if (n < GP_NB || n % GP_NB || extra_rows < 0 || extra_rows > GP_NB || extra_rows % GP_NB || workgroups < 1 || !ntasks) return GP_EINVAL;
+    mega_plan pl;
+    const int ob = GP_OUTER / GP_NB;
+    if (!chol_mega_plan(n, extra_rows, ob, workgroups, pl)) return GP_EINVAL;
+    // independent check of the list: replay it and count, per tile, the updates in the order the two-level scheme applies them
+    const int nb = n / GP_NB, nrow = (n + extra_rows) / GP_NB;
+    std::vector<int> upd((size_t)nrow * nb, 0), quarters((size_t)nrow * nb, 0), solved((size_t)nrow * nb, 0), fact(nb, 0);
+    auto expected = [&](int i, int j) { const int J = j / ob; return J + (j - J * ob); };      // outer updates of the panels before j's, then the in-panel ones
+    for (size_t p2 = 0; p2 < pl.tasks.size(); ++p2) {
+        const mega_task &t = pl.tasks[p2];
+        for (int d = 0; d < 10; ++d) if (t.dep[d] >= (int)p2) return GP_EINVAL;
+        if (t.type == 3) continue;                       // a place holder: announced by the fused task that names it
+        if (t.type == 0) { if (upd[(size_t)t.k0 * nb + t.k0] != expected(t.k0, t.k0) || fact[t.k0]++) return GP_EINVAL; }
+        else if (t.type == 4) {
+            // link + diagonal block: solves rows k of block column k-1 (after all ITS updates), applies the last in-panel update to tile (k, k)
+            const int k = t.k0;
+            if (k == 0 || k % ob == 0 || !fact[k - 1] || upd[(size_t)k * nb + (k - 1)] != expected(k, k - 1) || solved[(size_t)k * nb + (k - 1)]++) return GP_EINVAL;
+            if (t.q < 0 || t.q >= (int)pl.tasks.size() || pl.tasks[t.q].type != 3 || (size_t)t.q <= p2) return GP_EINVAL;   // its place holder follows it in the list
+            if (++upd[(size_t)k * nb + k] != expected(k, k) || fact[k]++) return GP_EINVAL;
+        }
+        else if (t.type == 1) { if (!fact[t.k0] || upd[(size_t)t.i * nb + t.k0] != expected(t.i, t.k0) || solved[(size_t)t.i * nb + t.k0]++) return GP_EINVAL; }
+        else {
+            for (int kk = t.k0; kk < t.k0 + t.kb; ++kk) if (!solved[(size_t)t.i * nb + kk] || (t.j < nb && t.i != t.j && !solved[(size_t)t.j * nb + kk])) return GP_EINVAL;
+            int &qd = quarters[(size_t)t.i * nb + t.j];
+            const int need = t.q < 0 ? 1 : (t.i == t.j ? 3 : 4);
+            if (++qd == need) { qd = 0; ++upd[(size_t)t.i * nb + t.j]; }
+        }
+    }
+    for (int k = 0; k < nb; ++k) if (!fact[k]) return GP_EINVAL;
+    for (int j = 0; j < nb; ++j) for (int i = j + 1; i < nrow; ++i) if (!solved[(size_t)i * nb + j]) return GP_EINVAL;
+    *ntasks = (int)pl.tasks.size();
+    if (model_us) *model_us = pl.model_us;
     return GP_OK;
 }
 

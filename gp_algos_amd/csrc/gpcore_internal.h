@@ -161,7 +161,10 @@ int gpk_init_diag_kernels();
 int gpk_init_gemm_kernels();
 // MFMA-blocked critical-path kernels (kernels_diag.hip).  dinv holds the inverses of the 16x16 diagonal
 // tiles of L: tile b (rows 16b..16b+15) at dinv + 256*b, element (c,k) at c + 16k; a 128-block owns 8 tiles.
-void gpk_potrf_diag128(hipStream_t s, double *A, int lda, double *dinv_k, int *d_info, int base, gp_batch bt = gp_batch());   // strides: A, dinv; d_info + 1 per problem
+void gpk_potrf_diag128(hipStream_t s, double *A, int lda, double *dinv_k, int *d_info, int base, gp_batch bt = gp_batch());
+// the whole two-level factorisation of one matrix as one persistent launch over a task list (16 ints per task: kernels_diag.hip chol_task)
+void gpk_chol_mega(hipStream_t s, int num_cu, double *A, int lda, double *dinv, int *d_info, const int *tasks, int ntasks, int *done, int *counter,
+                   int epoch, int *err, unsigned long long *stamps = nullptr);   // stamps: lab, 4 x 8 bytes per task   // strides: A, dinv; d_info + 1 per problem
 // optional fused row reductions: sumsq[p] += sum_c X(p,c)^2 ; dots[p] += sum_c X(p,c) tvec[c]
 // EP: the 128 rows of the delayed columns that belong to the next site block (X <- X Lmat^-T in place, X2 = X diag(cs2), dots += X tvec)
 // and the 128 x 128 lower tile D -= X2 X^T the next block kernel reads, one workgroup (kernels_diag.hip)

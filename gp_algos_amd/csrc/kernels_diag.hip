@@ -517,18 +517,394 @@ __global__ __launch_bounds__(64) void tile_inverse_kernel(const double *__restri
     }
 }
 
+// -------------------------------------------------------------------------------------------------
+// The whole blocked factorisation of ONE matrix as ONE persistent launch (round 4): a task list instead of ~250 launches.
+//
+// What the launch-per-step form cannot do is run throughput work beside the serial chain at a finer grain than a kernel: the far
+// trailing update and the next panel's chain share the chip as two kernels, the chain's whole-chip launches queue behind the
+// update's workgroups (2-4x slower), and late in the factorisation the chip idles through every diagonal block.
+// Here one workgroup per CU (512 threads, the diagonal-block kernel's 150 KB of LDS) takes tasks off a list, in list order, until the
+// list is empty:
+//   POTRF(k)            the diagonal block (potrf_block_body, as potrf_diag128_kernel); inside an outer panel with its link to the block
+//                       before as the prologue (mega_potrf_link: the solve of its own rows and its last in-panel update, fused);
+//   TRSM(k, i)          row block i of block column k:  X <- X L_kk^-T  (128 rows: the strip solve of trsm_panel128 / ep_link);
+//   UPD(k0, kb, i, j)   tile (i, j) -= X[i, k0..k0+kb) X[j, k0..k0+kb)^T  with K = 128 kb: the in-panel updates (kb = 1) and the outer
+//                       updates (kb = 4) of the two-level scheme -- the SAME products in the SAME order per element as the launches of
+//                       chol_blocked, so the factor is bit-identical to the one-stream form; a tile on the chain's way (the next
+//                       diagonal block's) is cut into 64 x 64 quarters that four workgroups take (q >= 0).
+// A task names the (at most ten) tasks whose results it reads or overwrites; `done[t] == epoch` says task t is in memory.  Publish:
+// every wave drains its stores, barrier, one lane: agent-scope release, drain, relaxed flag store.  Consume: one lane polls relaxed
+// (bounded: under a second, then *err is set and every workgroup falls through to the end -- a loud GP_EHIP, not a hung queue), agent-scope
+// acquire, drain, barrier, plain loads (MI355X_MICROARCH.md: the per-XCD L2s are not coherent with each other).
+// No deadlock: tasks are claimed in list order by workgroups that are running, the list is a topological order (checked on the
+// host), so everything a claimed task waits for was claimed earlier by a workgroup that is resident and will finish.
+// The ORDER of the list is a list schedule computed on the host from a cost model (critical path first: chol_mega_plan): claimed in
+// that order the dependencies are mostly met on arrival, and what waits is what the model would have idle anyway.
+struct chol_task { int type, k0, kb, i, j, q, dep[10]; };   // 64 bytes; type 0 POTRF (k0), 1 TRSM (k0, i), 2 UPD, 3 a place holder, 4 link + POTRF (k0; q = the place holder it announces)
+constexpr int MEGA_THREADS = 512;
+
+// tile (128 x 128 at Cp) -= A (128 x K at Ap) B (128 x K at Bp)^T, all with leading dimension ld: gemm_nt_f64_kernel's loop (8 waves x
+// 64 x 32, BK = 16, LDS-DMA double buffer) on the workgroup's dynamic LDS.  diag: elements above the diagonal are neither read nor
+// written.  quarter q >= 0: only the 64 x 64 quarter (row half q & 1, column half q >> 1) is computed and stored, by all eight waves.
+__device__ __noinline__ void mega_gemm_tile(const double *__restrict__ Ap, const double *__restrict__ Bp, double *__restrict__ Cp,
+                                            int ld, int K, bool diag, int quarter) {
+    // (each task body is a function of its own: inlined into one kernel the three of them need more than the 256 registers a wave of
+    // a 512-thread workgroup can have, and the diagonal block's serial chain is the last place for scratch traffic; the dynamic LDS is
+    // named here again rather than passed, so that the compiler keeps LDS addressing)
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int tid = threadIdx.x;
+    constexpr int TKm = 16, STR = 144;
+    double *As = sm, *Bs = sm + 2 * TKm * STR;
+    const int lane = tid & 63, wave = tid >> 6, fr = lane & 15, fk = lane >> 4;
+    const double *Asrc = Ap + lane * 2 + (size_t)wave * ld, *Bsrc = Bp + lane * 2 + (size_t)wave * ld;
+    auto stage = [&](int buf, int kt) {
+        const size_t koff = (size_t)kt * TKm;
+#pragma unroll
+        for (int q = 0; q < TKm / 8; ++q) {
+            __builtin_amdgcn_global_load_lds(Asrc + (koff + 8 * q) * ld, As + (buf * TKm + wave + 8 * q) * STR, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(Bsrc + (koff + 8 * q) * ld, Bs + (buf * TKm + wave + 8 * q) * STR, 16, 0, 0);
+        }
+    };
+    const int KT = K / TKm;
+    if (quarter >= 0) {
+        // A quarter is on the chain's way (the next diagonal block's tile): all eight waves share its 64 x 64 -- wave w: rows 16 (w & 3),
+        // columns 32 (w >> 2), two accumulators -- so its k loop is a quarter of a full tile's instead of the same length on two waves.
+        // Same products in the same k order per element as the full tile.
+        const int wr = 64 * (quarter & 1) + 16 * (wave & 3), wc = 64 * (quarter >> 1) + 32 * (wave >> 2);
+        double4_t acc[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+        stage(0, 0);
+        __syncthreads();
+        for (int kt = 0; kt < KT; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < KT) stage(cur ^ 1, kt + 1);
+            const double *Ac = As + cur * TKm * STR + wr + fr, *Bc = Bs + cur * TKm * STR + wc + fr;
+#pragma unroll
+            for (int ks = 0; ks < TKm / 4; ++ks) {
+                const double af = Ac[(ks * 4 + fk) * STR];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) acc[u] = MFMA(Bc[(ks * 4 + fk) * STR + u * 16], af, acc[u]);
+            }
+            __syncthreads();
+        }
+        const int m = wr + fr;
+        double cv[2][4];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = wc + nt * 16 + fk + 4 * r;
+                cv[nt][r] = (diag && m < n) ? 0.0 : Cp[m + (size_t)n * ld];
+            }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = wc + nt * 16 + fk + 4 * r;
+                const double v = fma(1.0, cv[nt][r], -1.0 * acc[nt][r]);
+                if (!(diag && m < n)) Cp[m + (size_t)n * ld] = v;
+            }
+        return;
+    }
+    const int wm = (wave & 1) * 64, wn = (wave >> 1) * 32;
+    double4_t acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    stage(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < KT; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < KT) stage(cur ^ 1, kt + 1);
+        const double *Ac = As + cur * TKm * STR + wm + fr, *Bc = Bs + cur * TKm * STR + wn + fr;
+#pragma unroll
+        for (int ks = 0; ks < TKm / 4; ++ks) {
+            double af[4], bf[2];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) af[u] = Ac[(ks * 4 + fk) * STR + u * 16];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) bf[u] = Bc[(ks * 4 + fk) * STR + u * 16];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = MFMA(bf[nt], af[mt], acc[nt][mt]);
+        }
+        __syncthreads();
+    }
+    // acc[nt][mt][r] = sum over k for (m = wm + 16 mt + fr, n = wn + 16 nt + fk + 4 r): C <- 1.0 * C + (-1.0) * acc, as gemm_nt_f64_kernel
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        double cv[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = wn + nt * 16 + fk + 4 * r;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const int m = wm + mt * 16 + fr;
+                cv[r][mt] = (diag && m < n) ? 0.0 : Cp[m + (size_t)n * ld];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = wn + nt * 16 + fk + 4 * r;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const int m = wm + mt * 16 + fr;
+                const double v = fma(1.0, cv[r][mt], -1.0 * acc[nt][mt][r]);
+                if (!(diag && m < n)) Cp[m + (size_t)n * ld] = v;
+            }
+        }
+    }
+}
+
+// X (128 rows x 128 columns at Xp, leading dimension ld) <- X L^-T, L at Lp (same ld), its tile inverses at dv: eight waves x 16 rows,
+// the strip in LDS with column stride LKS -- per row the arithmetic of trsm_panel128_kernel (trsm_chunk)
+__device__ __noinline__ void mega_trsm_rows(double *__restrict__ Xp, const double *__restrict__ Lp, const double *__restrict__ dv, int ld) {
+    extern __shared__ __attribute__((aligned(16))) double xs[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
+    const int li = (tid & 63) * 2, lc = tid >> 6;
+    {
+        const double *src = Xp + lane * 2 + (size_t)wave * ld;
+#pragma unroll
+        for (int q = 0; q < NB / 8; ++q) __builtin_amdgcn_global_load_lds(src + (size_t)(8 * q) * ld, xs + (wave + 8 * q) * LKS, 16, 0, 0);
+    }
+    double fa[28], fb[28];
+    trsm_load_frags<1>(Lp, ld, fr, fg, fa);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+    const int sp = wave * 16 + fr;
+    double ss = 0.0;
+    trsm_load_frags<2>(Lp, ld, fr, fg, fb);
+    trsm_chunk<0, LKS>(xs, sp, fr, fg, fa, dv, ss);
+    trsm_chunk<1, LKS>(xs, sp, fr, fg, fa, dv, ss);
+    trsm_load_frags<3>(Lp, ld, fr, fg, fa);
+    trsm_chunk<2, LKS>(xs, sp, fr, fg, fb, dv, ss);
+    trsm_load_frags<4>(Lp, ld, fr, fg, fb);
+    trsm_chunk<3, LKS>(xs, sp, fr, fg, fa, dv, ss);
+    trsm_load_frags<5>(Lp, ld, fr, fg, fa);
+    trsm_chunk<4, LKS>(xs, sp, fr, fg, fb, dv, ss);
+    trsm_load_frags<6>(Lp, ld, fr, fg, fb);
+    trsm_chunk<5, LKS>(xs, sp, fr, fg, fa, dv, ss);
+    trsm_load_frags<7>(Lp, ld, fr, fg, fa);
+    trsm_chunk<6, LKS>(xs, sp, fr, fg, fb, dv, ss);
+    trsm_chunk<7, LKS>(xs, sp, fr, fg, fa, dv, ss);
+    (void)ss;
+    __syncthreads();
+#pragma unroll 4
+    for (int q = 0; q < 16; ++q)
+        *reinterpret_cast<double2_t *>(Xp + li + (size_t)(lc + 8 * q) * ld) = *reinterpret_cast<const double2_t *>(xs + (lc + 8 * q) * LKS + li);
+}
+
+// the diagonal block, exactly as potrf_diag128_kernel does it (masked LDS-DMA load of the lower part, potrf_block_body)
+__device__ __noinline__ void mega_potrf_block(double *__restrict__ Akk, int lda, double *__restrict__ dinvk, int *info, int base) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
+    double *a = sm, *dv = sm + NB * PLS;
+    int *flag = reinterpret_cast<int *>(dv + 256);
+    if (tid == 0) *flag = 0;
+    const double *src = Akk + lane * 2;
+    if (wave == 0) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (lane * 2 + 1 >= j) __builtin_amdgcn_global_load_lds(src + (size_t)j * lda, a + j * PLS, 16, 0, 0);
+    } else {
+        for (int j = 16 + (wave - 1); j < NB; j += POTRF_WAVES - 1)
+            if (lane * 2 + 1 >= j) __builtin_amdgcn_global_load_lds(src + (size_t)j * lda, a + j * PLS, 16, 0, 0);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    potrf_block_body(a, dv, flag, Akk, lda, dinvk, info, base, tid, lane, wave, fr, fg);
+}
+
+// Diagonal block k INSIDE an outer panel (k > the panel's first block), with its link to the step before as the prologue: this block's
+// 128 rows of block column k-1 are solved here, X = A[blk k, blk k-1] L_{k-1,k-1}^-T (what TRSM(k-1, k) would do: the strip solve of
+// mega_trsm_rows), stored and ANNOUNCED (done[aux] = epoch: the tasks that multiply by these rows start now), the block's last in-panel
+// update D = A[blk k, blk k] - X X^T is formed from the strip still in LDS (36 lower 16 x 16 tiles over the eight waves, K = 128,
+// accumulated from zero and subtracted at the end -- element for element the arithmetic of the GEMM tile it replaces) and dropped into
+// the LDS image the factorisation starts from.  On the chain this is one task and ~20 us where panel solve, hand-over, quarter
+// update and hand-over were ~45.  (Round 3's potrf_link128_kernel did the same as a launch; there the rest of the panel had to wait
+// on a helper stream, here it is just more tasks.)
+__device__ __noinline__ void mega_potrf_link(double *__restrict__ A, int lda, double *__restrict__ dinv, int *info, int base, int *__restrict__ done_aux, int epoch) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double *a = sm;                 // NB x PLS: first the strip X, then the block D
+    double *dv = sm + NB * PLS;
+    int *flag = reinterpret_cast<int *>(dv + 256);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    if (tid == 0) *flag = 0;
+    double *X = A - (size_t)NB * lda;                       // rows of this block, columns of the block before
+    const double *Lp = A - NB - (size_t)NB * lda;           // the diagonal block before (factored) ...
+    const double *dp = dinv - 8 * 256;                      // ... and its tile inverses
+    {
+        const double *src = X + lane * 2 + (size_t)wave * lda;
+#pragma unroll
+        for (int q = 0; q < NB / 8; ++q) __builtin_amdgcn_global_load_lds(src + (size_t)(8 * q) * lda, a + (wave + 8 * q) * PLS, 16, 0, 0);
+    }
+    // this wave's tiles of D (q = wave, wave + 8, ...; at most 5): fetched now, under the solve
+    double4_t dold[5];
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+        const int q = wave + 8 * u;
+        int I = 0, J = 0;
+        if (q < 36) tri_coords(q, I, J);
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) dold[u][rr] = (q < 36) ? A[(16 * I + fr) + (size_t)(16 * J + fg + 4 * rr) * lda] : 0.0;
+    }
+    double fa[28], fb[28];
+    trsm_load_frags<1>(Lp, lda, fr, fg, fa);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+    const int sp = wave * 16 + fr;
+    double ss = 0.0;
+    trsm_load_frags<2>(Lp, lda, fr, fg, fb);
+    trsm_chunk<0, PLS>(a, sp, fr, fg, fa, dp, ss);
+    trsm_chunk<1, PLS>(a, sp, fr, fg, fa, dp, ss);
+    trsm_load_frags<3>(Lp, lda, fr, fg, fa);
+    trsm_chunk<2, PLS>(a, sp, fr, fg, fb, dp, ss);
+    trsm_load_frags<4>(Lp, lda, fr, fg, fb);
+    trsm_chunk<3, PLS>(a, sp, fr, fg, fa, dp, ss);
+    trsm_load_frags<5>(Lp, lda, fr, fg, fa);
+    trsm_chunk<4, PLS>(a, sp, fr, fg, fb, dp, ss);
+    trsm_load_frags<6>(Lp, lda, fr, fg, fb);
+    trsm_chunk<5, PLS>(a, sp, fr, fg, fa, dp, ss);
+    trsm_load_frags<7>(Lp, lda, fr, fg, fa);
+    trsm_chunk<6, PLS>(a, sp, fr, fg, fb, dp, ss);
+    trsm_chunk<7, PLS>(a, sp, fr, fg, fa, dp, ss);
+    (void)ss;
+    __syncthreads();
+    {   // the solved rows go back in place now: the stores drain while the matrix cores run the tile update
+        const int li = lane * 2, lc = wave;
+#pragma unroll 8
+        for (int q = 0; q < NB / 8; ++q)
+            *reinterpret_cast<double2_t *>(X + li + (size_t)(lc + 8 * q) * lda) = *reinterpret_cast<const double2_t *>(a + (lc + 8 * q) * PLS + li);
+    }
+    double4_t dnew[5];
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+        const int q = wave + 8 * u;
+        dnew[u] = dold[u];
+        if (q < 36) {
+            int I, J;
+            tri_coords(q, I, J);
+            double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 8
+            for (int ks = 0; ks < 32; ++ks) {
+                const int k = 4 * ks + fg;
+                acc = MFMA(a[k * PLS + 16 * J + fr], a[k * PLS + 16 * I + fr], acc);     // acc[rr]: (m = 16 I + fr, n = 16 J + fg + 4 rr)
+            }
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) dnew[u][rr] = fma(1.0, dold[u][rr], -1.0 * acc[rr]);
+        }
+        if (u == 0) {
+            // every wave's stores of X have had a tile's time to drain: announce the solved rows now, not after the whole update
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 64) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(done_aux, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+    __syncthreads();                      // nobody reads the strip any more
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+        const int q = wave + 8 * u;
+        if (q >= 36) break;
+        int I, J;
+        tri_coords(q, I, J);
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) a[(16 * I + fr) + (16 * J + fg + 4 * rr) * PLS] = dnew[u][rr];
+    }
+    // (the first barrier of the factorisation orders these writes before anybody reads them)
+    potrf_block_body(a, dv, flag, A, lda, dinv, info, base, tid, lane, wave, fr, fg);
+}
+
+__global__ __launch_bounds__(MEGA_THREADS, 1) void chol_mega_kernel(double *__restrict__ A, int lda, double *__restrict__ dinv, int *info,
+                                                                 const chol_task *__restrict__ tasks, int ntasks, int *__restrict__ done,
+                                                                 int *__restrict__ counter, int epoch, int *__restrict__ err, int mode,
+                                                                 unsigned long long *__restrict__ stamps) {
+    __shared__ int s_task;
+    const int tid = threadIdx.x;
+    // Control flow is kept UNIFORM: the loop runs on a scalar task index, and every lane-0 block sits between two barriers of its own.
+    // (A first version claimed at the top of the loop and published at the bottom, both under `if (tid == 0)` with no barrier between
+    // them across the back edge: hipcc merged the two blocks into one divergent region and structurised the loop so that lane 0 left
+    // it alone -- the other 511 threads went round again on the stale task index, for ever.)
+    if (tid == 0) s_task = atomicAdd(counter, 1);
+    __syncthreads();
+    int t = __builtin_amdgcn_readfirstlane(s_task);
+    __syncthreads();
+    while (t < ntasks) {
+        const chol_task tk = tasks[t];
+        if (tk.type == 3) {
+            // a place in the list for a result that a fused task announces half-way (mega_potrf_link): nothing to wait for, run or publish
+            if (tid == 0) s_task = atomicAdd(counter, 1);
+            __syncthreads();
+            t = __builtin_amdgcn_readfirstlane(s_task);
+            __syncthreads();
+            continue;
+        }
+        if (stamps && tid == 0) stamps[4 * (size_t)t] = __builtin_amdgcn_s_memrealtime();      // lab (GPCORE_MEGA_TRACE): claimed
+        if (tid == 0) {
+            for (int d = 0; d < 10; ++d) {
+                const int dep = tk.dep[d];
+                if (dep < 0) continue;
+                int it = 0;
+                while (__hip_atomic_load(done + dep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+                    if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                    if (++it > 400000) { atomicExch(err, 1 + t); break; }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        if (stamps && tid == 0) stamps[4 * (size_t)t + 1] = __builtin_amdgcn_s_memrealtime();  // dependencies met, acquire done
+        if (tk.type == 0) {
+            if (mode & 1)
+                mega_potrf_block(A + (size_t)tk.k0 * NB * ((size_t)lda + 1), lda, dinv + (size_t)tk.k0 * NB * 16, info, tk.k0 * NB);
+        } else if (tk.type == 1) {
+            if (mode & 2)
+                mega_trsm_rows(A + (size_t)tk.i * NB + (size_t)tk.k0 * NB * lda, A + (size_t)tk.k0 * NB * ((size_t)lda + 1),
+                               dinv + (size_t)tk.k0 * NB * 16, lda);
+        } else if (tk.type == 4) {
+            if (mode & 1)
+                mega_potrf_link(A + (size_t)tk.k0 * NB * ((size_t)lda + 1), lda, dinv + (size_t)tk.k0 * NB * 16, info, tk.k0 * NB, done + tk.q, epoch);
+        } else if (mode & 4)
+            mega_gemm_tile(A + (size_t)tk.i * NB + (size_t)tk.k0 * NB * lda, A + (size_t)tk.j * NB + (size_t)tk.k0 * NB * lda,
+                           A + (size_t)tk.i * NB + (size_t)tk.j * NB * lda, lda, tk.kb * NB, tk.i == tk.j, tk.q);
+        // publish: every wave's stores acknowledged, then ONE lane releases at agent scope, sets the flag -- and claims the next task
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            if (stamps) stamps[4 * (size_t)t + 2] = __builtin_amdgcn_s_memrealtime();                 // body done, stores acknowledged
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(done + t, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (stamps) stamps[4 * (size_t)t + 3] = __builtin_amdgcn_s_memrealtime() | ((unsigned long long)blockIdx.x << 48);   // published; who ran it
+            s_task = atomicAdd(counter, 1);
+        }
+        __syncthreads();
+        t = __builtin_amdgcn_readfirstlane(s_task);
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 static constexpr int POTRF_LDS = (NB * PLS + 256 + 8) * (int)sizeof(double);
 static constexpr int TRSM_LDS = NB * XS * (int)sizeof(double);
 static constexpr int STEP_LDS = (NB * LS1 + 8 * 256 + NB + 16) * (int)sizeof(double);
 static constexpr int LINK_LDS = NB * LKS * (int)sizeof(double);
+static constexpr int MEGA_LDS = POTRF_LDS > LINK_LDS ? POTRF_LDS : LINK_LDS;     // the diagonal block's image / the 128-row strip / 72 KB of GEMM staging
 
 int gpk_init_diag_kernels() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(potrf_diag128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, POTRF_LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(trsm_panel128_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, TRSM_LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(trsm_panel128_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, TRSM_LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(ep_link_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LINK_LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(chol_mega_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, MEGA_LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(fwd_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, STEP_LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(bwd_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, STEP_LDS);
     return e == hipSuccess ? 0 : 1;
@@ -545,6 +921,14 @@ void gpk_trsm_panel128(hipStream_t s, double *X, int M, int ldx, const double *L
         hipLaunchKernelGGL(trsm_panel128_kernel<true>, dim3(M / 64, bt.count), dim3(256), TRSM_LDS, s, X, ldx, Lkk, ldl, dinv, sumsq, tvec, dots, bt, X2, cs2);
     else
         hipLaunchKernelGGL(trsm_panel128_kernel<false>, dim3(M / 64, bt.count), dim3(256), TRSM_LDS, s, X, ldx, Lkk, ldl, dinv, sumsq, tvec, dots, bt, X2, cs2);
+}
+// tasks: ntasks x 16 ints (chol_task), done: ntasks ints, counter / err: one int each (counter zeroed by the caller in stream order)
+void gpk_chol_mega(hipStream_t s, int num_cu, double *A, int lda, double *dinv, int *d_info, const int *tasks, int ntasks, int *done, int *counter,
+                   int epoch, int *err, unsigned long long *stamps) {
+    const int grid = ntasks < num_cu ? ntasks : num_cu;
+    static const int mode = [] { const char *e = getenv("GPCORE_MEGA_MODE"); return e ? atoi(e) : 7; }();   // lab: which task bodies run
+    hipLaunchKernelGGL(chol_mega_kernel, dim3(grid), dim3(MEGA_THREADS), MEGA_LDS, s, A, lda, dinv, d_info, reinterpret_cast<const chol_task *>(tasks),
+                       ntasks, done, counter, epoch, err, mode, stamps);
 }
 void gpk_ep_link(hipStream_t s, double *X, int ldx, const double *Lmat, const double *dinv, const double *tvec, double *dots, double *X2,
                  const double *cs2, double *D, int ldd) {

@@ -68,6 +68,12 @@ gp_status gp_ctx_profile_read(gp_ctx *ctx, int which, int64_t *launches, double 
  * panel's factorisation): 1 on, 0 off, -1 (default) chosen by size.  Per-kernel timings (gp_ctx_profile) of overlapping launches
  * add up to more than the wall time, so a measurement of the trailing-update kernel alone switches it off. */
 gp_status gp_ctx_set_lookahead(gp_ctx *ctx, int mode);
+/* The task list behind the single-launch form of the factorisation (breeze.linalg.cholesky, gp/regression/GpPredictor.scala:120, for ONE
+ * matrix of n (padded) rows with `extra_rows` riding along, outer panels of 512 columns): HOST ONLY, no device -- builds the list for
+ * `workgroups` workers, verifies it (every tile of the two-level right-looking scheme updated by every panel, in order; every
+ * dependency pointing backwards in the list) and returns its length and the makespan of the schedule under the cost model, in us.
+ * GP_EINVAL for a shape the single-launch form does not take. */
+gp_status gp_chol_plan_info(int n, int extra_rows, int workgroups, int *ntasks, double *model_us);
 /* fp64 MFMA peak probe: runs a register-only v_mfma_f64_16x16x4_f64 loop on every CU and returns
  * the measured TFLOP/s (denominator check for roofline fractions). */
 gp_status gp_probe_mfma_f64(gp_ctx *ctx, double *tflops);

@@ -56,3 +56,24 @@ def test_no_gpu_means_loud_failure(lib):
     from gp_algos_amd.core import Context
     with pytest.raises(_lib.GpCoreError):
         Context(0)
+
+
+def test_single_launch_cholesky_plan_is_a_valid_schedule():
+    """gp_chol_plan_info (host only): the task list of the single-launch factorisation for several shapes -- every block factored once,
+    every row block solved once after its updates, every tile updated by every panel in order, every dependency pointing backwards --
+    and the makespan of its schedule under the cost model (the figure DESIGN.md section 7 compares the measured fit with)."""
+    import ctypes as C
+    from gp_algos_amd import _lib as L
+    lib = L.load()
+    nt, us = C.c_int(), C.c_double()
+    seen = {}
+    for n, extra, wg in ((2048, 128, 256), (2560, 0, 256), (4096, 128, 256), (8192, 128, 256), (8192, 0, 64), (3200, 128, 7)):
+        assert lib.gp_chol_plan_info(n, extra, wg, C.byref(nt), C.byref(us)) == L.GP_OK, (n, extra, wg)
+        nb, nrow = n // 128, (n + extra) // 128
+        assert nt.value >= nb + sum(nrow - k - 1 for k in range(nb)) and us.value > 0.0
+        seen[(n, extra, wg)] = (nt.value, us.value)
+    assert seen[(8192, 0, 64)][1] > seen[(8192, 128, 256)][1]                    # a quarter of the workgroups: a longer schedule
+    assert 3000.0 < seen[(8192, 128, 256)][1] < 5000.0                           # the model's n = 8192: about 4 ms on 256 CUs
+    for bad in ((100, 0, 256), (8192, 64, 256), (8192, 256, 256), (8192, 0, 0)):
+        assert lib.gp_chol_plan_info(*bad, C.byref(nt), C.byref(us)) == L.GP_EINVAL
+    assert lib.gp_chol_plan_info(8192, 128, 256, None, None) == L.GP_EINVAL

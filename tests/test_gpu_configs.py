@@ -212,22 +212,27 @@ def test_ep_streamed_refactorisation_at_a_ragged_size(ctx, monkeypatch):
     assert abs(g["lml"] - got["0"]["lml"]) <= 1e-9 * abs(got["0"]["lml"])
 
 
-@pytest.mark.parametrize("n", [1100, 2500, 4000])
-def test_cholesky_lookahead_forms_agree_with_the_first_bad_pivot(ctx, n):
-    """The far trailing updates on the CU-masked side stream (look-ahead forced on) against the one-stream form at sizes with 3, 5 and 8
-    outer panels and a ragged last block: the same tiles by the same kernels, so the factor is IDENTICAL, and so is the first bad
-    pivot -- inside the first panel, inside a later panel, in the last block."""
+@pytest.mark.parametrize("n", [1100, 2500, 4000, 5200])
+def test_cholesky_single_launch_and_lookahead_forms_agree_with_the_first_bad_pivot(ctx, monkeypatch, n):
+    """The three ways a single matrix is factored -- ONE persistent launch over a task list (chol_mega_kernel, round 4: default where
+    look-ahead is on and np >= 2048), the launch-per-step form with the far trailing updates on the CU-masked side stream, and the
+    one-stream form -- apply the same products in the same order per element, so the factor is IDENTICAL, and so is the first bad
+    pivot: inside the first panel, inside a later panel, in the last block.  3 / 5 / 8 / 11 outer panels, ragged last blocks."""
     from gp_algos_amd import _lib as L
     p = synth.regression(n, 3, 0, 5, 6, 0, synth.ard_theta(3, 1.3, 0.9, 0.3))
     K = orc.gram_sym(p["X"], p["theta"])
     lib = ctx._lib
+    modes = (("1", 1), ("0", 1), ("0", 0))          # (GPCORE_CHOL_MEGA, look-ahead)
     try:
-        ctx.check(lib.gp_ctx_set_lookahead(ctx.h, 1))
-        ahead = [ctx.potrf_lower(K.copy(order="F")) for _ in range(2)]
-        ctx.check(lib.gp_ctx_set_lookahead(ctx.h, 0))
-        one = ctx.potrf_lower(K.copy(order="F"))
-        for g in ahead:
-            assert np.array_equal(g, one)
+        got = []
+        for mega, la in modes:
+            monkeypatch.setenv("GPCORE_CHOL_MEGA", mega)
+            ctx.check(lib.gp_ctx_set_lookahead(ctx.h, la))
+            got.append([ctx.potrf_lower(K.copy(order="F")) for _ in range(2)])
+        one = got[-1][0]
+        for pair in got:
+            for g in pair:
+                assert np.array_equal(g, one)
         assert np.all(np.triu(one, 1) == 0.0)
         assert np.linalg.norm(one @ one.T - K) / np.linalg.norm(K) <= 1e-13
         if n <= 1100:
@@ -236,11 +241,16 @@ def test_cholesky_lookahead_forms_agree_with_the_first_bad_pivot(ctx, n):
         for j in (n - 7, 700, 130):
             Kbad = K.copy(order="F")
             Kbad[j, j] = -1.0
-            for la in (1, 0):
+            for mega, la in modes:
+                monkeypatch.setenv("GPCORE_CHOL_MEGA", mega)
                 ctx.check(lib.gp_ctx_set_lookahead(ctx.h, la))
                 with pytest.raises(L.NotPositiveDefinite) as ei:
                     ctx.potrf_lower(Kbad.copy(order="F"))
                 assert ei.value.info == j + 1
+        # and a healthy factorisation right after the failing ones (the flags of the task list are per launch)
+        monkeypatch.setenv("GPCORE_CHOL_MEGA", "1")
+        ctx.check(lib.gp_ctx_set_lookahead(ctx.h, 1))
+        assert np.array_equal(ctx.potrf_lower(K.copy(order="F")), one)
     finally:
         ctx.check(lib.gp_ctx_set_lookahead(ctx.h, -1))
 
@@ -256,7 +266,7 @@ def test_cholesky_lookahead_on_the_side_stream_is_the_same_factorisation(ctx):
     lib = ctx._lib
     got = {}
     for la in (1, 0):
-        ctx.check(lib.gp_ctx_set_lookahead(ctx.h, la))
+        ctx.check(lib.gp_ctx_set_lookahead(ctx.h, la))            # la = 1: the single persistent launch (the y^T strip riding along as a 51st row block)
         m = RegressionModel(ctx, p["X"], p["y"], p["theta"])
         for _ in range(3):                                          # refits queued without a host sync in between
             ctx.check(lib.gp_model_refit_dev(m.h, L.dptr(L.f64(p["theta"])), float("nan")))
