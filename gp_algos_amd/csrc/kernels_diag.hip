@@ -778,11 +778,9 @@ __device__ __noinline__ void mega_potrf_link(double *__restrict__ A, int lda, do
         for (int q = 0; q < NB / 8; ++q)
             *reinterpret_cast<double2_t *>(X + li + (size_t)(lc + 8 * q) * lda) = *reinterpret_cast<const double2_t *>(a + (lc + 8 * q) * PLS + li);
     }
-    double4_t dnew[5];
 #pragma unroll
     for (int u = 0; u < 5; ++u) {
         const int q = wave + 8 * u;
-        dnew[u] = dold[u];
         if (q < 36) {
             int I, J;
             tri_coords(q, I, J);
@@ -793,7 +791,7 @@ __device__ __noinline__ void mega_potrf_link(double *__restrict__ A, int lda, do
                 acc = MFMA(a[k * PLS + 16 * J + fr], a[k * PLS + 16 * I + fr], acc);     // acc[rr]: (m = 16 I + fr, n = 16 J + fg + 4 rr)
             }
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) dnew[u][rr] = fma(1.0, dold[u][rr], -1.0 * acc[rr]);
+            for (int rr = 0; rr < 4; ++rr) dold[u][rr] = fma(1.0, dold[u][rr], -1.0 * acc[rr]);      // from here on: the updated tile
         }
         if (u == 0) {
             // every wave's stores of X have had a tile's time to drain: announce the solved rows now, not after the whole update
@@ -814,7 +812,7 @@ __device__ __noinline__ void mega_potrf_link(double *__restrict__ A, int lda, do
         int I, J;
         tri_coords(q, I, J);
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) a[(16 * I + fr) + (16 * J + fg + 4 * rr) * PLS] = dnew[u][rr];
+        for (int rr = 0; rr < 4; ++rr) a[(16 * I + fr) + (16 * J + fg + 4 * rr) * PLS] = dold[u][rr];
     }
     // (the first barrier of the factorisation orders these writes before anybody reads them)
     potrf_block_body(a, dv, flag, A, lda, dinv, info, base, tid, lane, wave, fr, fg);

@@ -24,5 +24,42 @@ def test_no_kernel_uses_scratch(src, tmp_path):
     names = re.findall(r"Function Name: (\S+)", out.stderr)
     scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", out.stderr)]
     assert names and len(names) == len(scratch)
-    spilled = {n: s for n, s in zip(names, scratch) if s}
+    # chol_mega_kernel calls its task bodies as real functions (inlined into one kernel they need more than a wave's 256 registers): its
+    # scratch is their call frames -- callee-saved registers stored at function entry and reloaded at exit, once per TASK -- and is
+    # checked for exactly that below
+    spilled = {n: s for n, s in zip(names, scratch) if s and "chol_mega_kernel" not in n}
     assert not spilled, "kernels spilling to scratch: %r" % spilled
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC) and shutil.which("hipcc") is None, reason="hipcc not available")
+def test_single_launch_cholesky_scratch_is_call_frames_only(tmp_path):
+    """The task bodies of chol_mega_kernel (mega_potrf_block / mega_potrf_link / mega_trsm_rows / mega_gemm_tile) may touch scratch
+    only to save callee-saved registers on entry and restore them on exit: in each function every scratch store precedes the first
+    barrier / matrix instruction and every scratch load follows the last one -- nothing spills inside a task, least of all inside the
+    diagonal block's pivot chain -- and the kernel itself reports no spilled register."""
+    src = os.path.join(ROOT, "gp_algos_amd", "csrc", "kernels_diag.hip")
+    asm = tmp_path / "kd.s"
+    out = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage",
+                          "-o", str(asm), src], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    m = re.search(r"Function Name: \S*chol_mega_kernel\S*(?:.|\n)*?VGPRs Spill: (\d+)", out.stderr)
+    assert m and int(m.group(1)) == 0
+    text = open(asm).read()
+    seen = 0
+    for fn in ("mega_potrf_block", "mega_potrf_link", "mega_trsm_rows", "mega_gemm_tile"):
+        mm = re.search(r"^(_ZN\S*%s\S*):\s*;.*?\n((?:.|\n)*?)\.Lfunc_end" % fn, text, flags=re.M)
+        assert mm, fn
+        lines = mm.group(2).split("\n")
+        is_work = lambda ln: re.search(r"\b(s_barrier|v_mfma_\w+|ds_read\w*|ds_write\w*|global_load_lds\w*)\b", ln) is not None
+        work = [i for i, ln in enumerate(lines) if is_work(ln)]
+        st = [i for i, ln in enumerate(lines) if "scratch_store" in ln]
+        ld = [i for i, ln in enumerate(lines) if "scratch_load" in ln]
+        ret = [i for i, ln in enumerate(lines) if "s_setpc_b64" in ln]
+        assert work and ret, fn
+        assert all(i < work[0] for i in st), "%s stores to scratch inside its body" % fn
+        for i in ld:          # a reload belongs to the epilogue: nothing but reloads and bookkeeping between it and the return
+            j = min(r for r in ret if r > i)
+            assert not any(is_work(ln) for ln in lines[i:j]), "%s loads from scratch inside its body" % fn
+        assert len(st) == len(ld)
+        seen += 1
+    assert seen == 4
