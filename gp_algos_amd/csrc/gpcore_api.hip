@@ -146,6 +146,21 @@ void gemm_sub_single(hipStream_t s, int M, int N, int K, const double *A, int ld
 // order the simulation starts them.  Workgroups claim tasks in list order, so on the chip the dependencies of a claimed task are
 // mostly met already and the chain (diagonal block with its link to the block before; at a panel boundary: solve of the next block's rows -> the quarters of the next diagonal tile) is
 // never waiting behind throughput work.  Every dependency points BACKWARDS in the list (checked): no deadlock.
+// What the static order leaves on the table, and what did not recover it (round 4, n = 8192 refit 4.9 ms with this list; the traces are
+// tools/mega_trace.py's, the variants are kept as tools/lab/mega_claim_ahead.patch):
+//   - the mean step from one diagonal block to the next is ~77 us against ~55 of task bodies: in some phases of the factorisation the
+//     chip is behind the model and the chain's tasks are claimed 10-60 us after their dependencies were met, in others it is ahead and
+//     they are claimed up to 400 us early (profiles/r04_i_mega_chain_detail.log);
+//   - the chain's tasks a fixed lead (0..200 us of model time) earlier in the list: 4.99-5.09 ms, the lag is not a constant
+//     (profiles/r04_k_fit_mega_lead_sweep.log);
+//   - the chain's tasks in a queue of their own whose head is taken, by compare-and-swap, by the first workgroup that finds it READY:
+//     nobody spins, but the head moves one task per poll of one workgroup (~2 us) and the 33 quarters behind a panel boundary are taken
+//     over 66 us: 5.63 ms (profiles/r04_j_*);
+//   - that queue claimed a bounded number of tasks AHEAD (4..64 outstanding) by workgroups that then wait: 5.27-6.03 ms, every
+//     outstanding task is a CU spinning and the late dependencies are one level further out, in the bulk (profiles/r04_l_*, r04_m_*:
+//     with every in-panel task of the next 2 / 4 / 8 block rows in the chain queue 5.47 / 5.53 / 5.65 ms);
+//   - block k's link given an early phase (the previous panel's earlier block columns applied before block k-1's factor arrives) and
+//     the first block of every panel fused the same way: 4.92-5.10 ms, no better (profiles/r04_i_fit_mega_lead_order.log is that variant).
 bool chol_mega_plan(int np, int extra, int out_blocks, int workers, mega_plan &plan) {
     const int nb = np / GP_NB, nrow = (np + extra) / GP_NB;
     struct node { mega_task t; double cost; std::vector<int> deps; };

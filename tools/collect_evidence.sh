@@ -4,7 +4,7 @@
 # throughput.  usage (from the repo root on the box): bash tools/collect_evidence.sh <tag> [quick|full] [first stage: 0 bench lines, 1 pmc c2/c3, 2 pmc c4/c5, 3 the rest]
 # Every step appends to $O/progress.log so that a long collection never looks hung.
 set -o pipefail
-TAG=${1:-r03_final}
+TAG=${1:-r04_final}
 QUICK=${2:-}
 FROM=${3:-0}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -36,8 +36,9 @@ fi
 if [ $FROM -le 2 ]; then
 # (c4: the fused chain kernel announces its solved rows to a kernel that waits on the side stream; under --pmc the profiler runs one
 #  kernel at a time, so the waiter would only ever time out -- the counters are taken on the two-launch form, same GEMM kernels, and
-#  without the ep_grid block, whose lockstep batch always runs the fused kernel)
-GPCORE_EP_FUSED=0 pmc c4 --workload c4 --steps 1 --no-c3
+#  without the ep_grid block, whose lockstep batch always runs the fused kernel; --no-roofline-events: with ~19 000 HIP event records
+#  outstanding between two host synchronisations the WRITE_SIZE pass of round 3 stopped, profiles/r04_b_pmc_c4_WRITE_SIZE_*.log)
+GPCORE_EP_FUSED=0 pmc c4 --workload c4 --steps 1 --no-c3 --no-roofline-events
 pmc c5 --workload c5 --steps 1 --warmup 1 --test-points 262144
 fi
 [ "$QUICK" = "quick" ] && exit 0
@@ -46,6 +47,9 @@ python3 $R/tools/trace_breakdown.py $(find $O/trace_c4 -name "*.db" | head -1) 1
 python3 $R/tools/sweep_summary.py $(find $O/trace_c4 -name "*.db" | head -1) > $O/c4_sweep_summary.txt 2>&1
 rm -rf $O/trace_c4
 python3 $R/tools/chain_kernels.py 8192 3 > $O/chain_kernels.log 2>&1 && say "chain kernels ok"
+# the factorisation alone, launch-per-step form against the single persistent launch, and where the single launch's time goes
+for n in 4096 6144 8192 10240 12288 16384; do for m in 0 1; do echo "== GPCORE_CHOL_MEGA=$m"; GPCORE_CHOL_MEGA=$m python3 $R/tools/fit_only.py $n 10; done; done > $O/fit_mega.log 2>&1; say "fit ok"
+python3 $R/tools/mega_trace.py 8192 > $O/mega_trace.log 2>&1 && say "mega trace ok"
 for n in 1024 2048 8192; do python3 $R/tools/ep_sweeps.py $n 8 >> $O/ep_sizes.log 2>&1; GPCORE_EP_FUSED=0 python3 $R/tools/ep_sweeps.py $n 8 >> $O/ep_sizes.log 2>&1; done; say "ep sizes ok"
 (GPCORE_EP_LOCKSTEP=0 python3 $R/tools/ep_mesh_perf.py 12 10 4096 1; python3 $R/tools/ep_mesh_perf.py 12 10 4096 1; GPCORE_EP_LOCKSTEP=0 python3 $R/tools/ep_mesh_perf.py 12 10 2048; python3 $R/tools/ep_mesh_perf.py 12 10 2048) > $O/ep_mesh_perf.log 2>&1; say "mesh ok"
 python3 $R/tools/gram_perf.py > $O/gram_perf.log 2>&1; say "gram ok"
