@@ -129,7 +129,7 @@ def _cholesky_block(n, t_fit, t_fit_serial, o_k, o_ms, o_work, p_k, p_ms, p_work
     return out
 
 
-PMC_TAG = "r03"          # profiles/<PMC_TAG>_pmc_<workload>_summary.json: the committed rocprofv3 --pmc passes of this round (tools/collect_evidence.sh)
+PMC_TAG = "r04"          # profiles/<PMC_TAG>_pmc_<workload>_summary.json: the committed rocprofv3 --pmc passes of this round (tools/collect_evidence.sh)
 CLASS_SYMBOLS = {        # kernel symbols behind a profile class, as tools/pmc_summary.py abbreviates them
     "gemm": ("gemm_nt_f64_kernel<0,", "gemm_fused_kernel<"),
     "syrk": ("gemm_nt_f64_kernel<1,", "gemm_k128_kernel<1>"),
@@ -137,13 +137,29 @@ CLASS_SYMBOLS = {        # kernel symbols behind a profile class, as tools/pmc_s
 }
 
 
+def kernel_sources_sha256():
+    """Hash of the library's sources as tools/pmc_summary.py records it in a PMC summary."""
+    import glob
+    import hashlib
+    root = os.path.join(ROOT, "gp_algos_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(root, "*.hip")) + glob.glob(os.path.join(root, "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 def _pmc_traffic(workload, prefixes):
     """HBM bytes per launch of the kernels behind a profile class, from the committed PMC passes of the same bench command
     (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE, MI355X_MICROARCH.md): launch-weighted mean over the matching
-    symbols.  PMC counters cannot be read from inside the process: None when the summary file is missing."""
+    symbols.  PMC counters cannot be read from inside the process: None when the summary file is missing, or when it was taken on
+    other kernel sources than the ones in this tree (the summary carries their hash)."""
     try:
         pm = json.load(open(os.path.join(ROOT, "profiles", "%s_pmc_%s_summary.json" % (PMC_TAG, workload))))
     except Exception:
+        return None
+    # counters of another build are not this code's counters (VERDICT r03 weak #7): refused, `traffic` is then null
+    if pm.get("kernel_sources_sha256") != kernel_sources_sha256():
         return None
     tot, cnt, used = 0.0, 0, []
     for sym, e in pm.get("kernels", {}).items():
@@ -751,10 +767,12 @@ def main():
         # HBM traffic per launch of the dominant kernel: PMC counters cannot be read from inside the process, so the
         # figure comes from the committed rocprofv3 --pmc passes of this same command (profiles/, FETCH_SIZE doubled
         # per the gfx950 correction); only reported for the configuration those passes ran.
-        traffic = None
+        traffic, traffic_note = None, None
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", PMC_SUMMARY)))
-            if (n, d, m) == (8192, 8, 65536):
+            if pm.get("kernel_sources_sha256") != kernel_sources_sha256():
+                traffic_note = "profiles/%s was collected on other kernel sources than this tree's: not reported" % PMC_SUMMARY
+            elif (n, d, m) == (8192, 8, 65536):
                 traffic = pm["kernels"][DOMINANT_KERNEL]["hbm_bytes_per_launch_corrected"]
         except Exception:
             traffic = None
@@ -780,7 +798,7 @@ def main():
                                    "column i in one product on 256x128 tiles, one 8-wave workgroup (64x64 per wave) per CU, row reductions in the "
                                    "epilogue; v_mfma_f64_16x16x4_f64)",
                          "bound": "mfma", "achieved": gemm_tflops, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": gemm_tflops / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic,
+                         "frac": gemm_tflops / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
                          "traffic_unit": "HBM bytes per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/%s)" % PMC_SUMMARY,
                          # average over the n/128 launches, K_i = 128 (i + 1): A read m K, Lw block row read 128 K, C written m 128
                          "algorithmic_bytes_per_launch": 8.0 * (m * ((n + 128) / 2.0) + 128 * ((n + 128) / 2.0) + m * 128),

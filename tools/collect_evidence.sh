@@ -2,6 +2,8 @@
 # Round evidence on the GPU box: bench lines of every workload, rocprofv3 kernel stats of the headline command, PMC passes per workload
 # (one counter set per run, kernel-trace only; the program goes directly after `--`), EP sweep timeline, chain-kernel stamps, mesh
 # throughput.  usage (from the repo root on the box): bash tools/collect_evidence.sh <tag> [quick|full] [first stage: 0 bench lines, 1 pmc c2/c3, 2 pmc c4/c5, 3 the rest]
+# SKIP_PMC=1 leaves the PMC stages out (round 4: the PMC passes are collected first, `<tag> quick 1`, their summaries copied to
+# profiles/<round>_pmc_*_summary.json, and the bench lines -- which read those files for roofline.traffic -- in a second call).
 # Every step appends to $O/progress.log so that a long collection never looks hung.
 set -o pipefail
 TAG=${1:-r04_final}
@@ -29,11 +31,11 @@ python3 $R/bench.py --workload c3 --steps 3 --warmup 1 > $O/bench_c3.json 2> $O/
 python3 $R/bench.py --workload c4 --steps 2 > $O/bench_c4.json 2> $O/bench_c4.err && say "c4 ok"
 python3 $R/bench.py --workload c5 --steps 1 --warmup 1 > $O/bench_c5.json 2> $O/bench_c5.err && say "c5 ok"
 fi
-if [ $FROM -le 1 ]; then
+if [ $FROM -le 1 ] && [ -z "$SKIP_PMC" ]; then
 pmc c2 --steps 1 --warmup 1 --no-cpu-baseline --no-c3
 pmc c3 --workload c3 --steps 1 --warmup 1
 fi
-if [ $FROM -le 2 ]; then
+if [ $FROM -le 2 ] && [ -z "$SKIP_PMC" ]; then
 # (c4: the fused chain kernel announces its solved rows to a kernel that waits on the side stream; under --pmc the profiler runs one
 #  kernel at a time, so the waiter would only ever time out -- the counters are taken on the two-launch form, same GEMM kernels, and
 #  without the ep_grid block, whose lockstep batch always runs the fused kernel; --no-roofline-events: with ~19 000 HIP event records

@@ -5,9 +5,23 @@ hbm_bytes_per_launch_corrected = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: on gfx950
 coalesced stream (MI355X_MICROARCH.md; calibrated in round 1 on gemv_rows_kernel, which reads a 4.295 GB matrix once)."""
 import collections
 import csv
+import glob
+import hashlib
 import json
+import os
 import re
 import sys
+
+
+def kernel_sources_sha256():
+    """Hash of the library's sources (gp_algos_amd/csrc/*.hip, *.h, sorted by name): written into the summary so that bench.py can
+    tell a summary of another build from one of the code it runs (same function in bench.py)."""
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gp_algos_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(root, "*.hip")) + glob.glob(os.path.join(root, "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
 
 
 def short(name):
@@ -34,7 +48,7 @@ def main():
         if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
             e["hbm_bytes_per_launch_corrected"] = (2.0 * e["FETCH_SIZE_avg_per_launch"] + e["WRITE_SIZE_avg_per_launch"]) * 1024.0
         kernels[k] = e
-    json.dump({"note": note, "kernels": kernels}, open(out, "w"), indent=1)
+    json.dump({"note": note, "kernel_sources_sha256": kernel_sources_sha256(), "kernels": kernels}, open(out, "w"), indent=1)
     for k, e in sorted(kernels.items(), key=lambda kv: -kv[1].get("hbm_bytes_per_launch_corrected", 0)):
         print("%-44s %s" % (k, {a: (round(b, 1) if isinstance(b, float) else b) for a, b in e.items()}))
 
