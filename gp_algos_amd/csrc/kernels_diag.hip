@@ -543,9 +543,14 @@ __global__ __launch_bounds__(64) void tile_inverse_kernel(const double *__restri
 struct chol_task { int type, k0, kb, i, j, q, dep[10]; };   // 64 bytes; type 0 POTRF (k0), 1 TRSM (k0, i), 2 UPD, 3 a place holder, 4 link + POTRF (k0; q = the place holder it announces)
 constexpr int MEGA_THREADS = 512;
 
-// tile (128 x 128 at Cp) -= A (128 x K at Ap) B (128 x K at Bp)^T, all with leading dimension ld: gemm_nt_f64_kernel's loop (8 waves x
-// 64 x 32, BK = 16, LDS-DMA double buffer) on the workgroup's dynamic LDS.  diag: elements above the diagonal are neither read nor
-// written.  quarter q >= 0: only the 64 x 64 quarter (row half q & 1, column half q >> 1) is computed and stored, by all eight waves.
+// tile (128 x 128 at Cp) -= A (128 x K at Ap) B (128 x K at Bp)^T, all with leading dimension ld: gemm_nt_f64_kernel's products (8 waves
+// x 64 x 32, BK = 16) on the workgroup's dynamic LDS.  diag: elements above the diagonal are neither read nor written.  quarter q >= 0:
+// only the 64 x 64 quarter (row half q & 1, column half q >> 1) is computed and stored, by all eight waves.
+// Staging: a RING of four k-slices filled by LDS-DMA three slices ahead.  The launch-per-step kernel gets by with two buffers because
+// two workgroups share a CU; here there is one, two waves per SIMD, and the tasks of 256 workgroups are spread over the matrix with no
+// two neighbours on the same XCD: the operands come from HBM, not L2 (PMC: 12.9 GB per factorisation, 24 x the matrix,
+// profiles/r04_final pmc_c2 first pass), and with the next slice requested only one slice ahead every k step waited for memory --
+// 2.46 us per step against 1.7 us of matrix-core time, a quarter (0.2 us of matrix-core time per step) 0.9 us.
 __device__ __noinline__ void mega_gemm_tile(const double *__restrict__ Ap, const double *__restrict__ Bp, double *__restrict__ Cp,
                                             int ld, int K, bool diag, int quarter) {
     // (each task body is a function of its own: inlined into one kernel the three of them need more than the 256 registers a wave of
@@ -553,12 +558,21 @@ __device__ __noinline__ void mega_gemm_tile(const double *__restrict__ Ap, const
     // named here again rather than passed, so that the compiler keeps LDS addressing)
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int tid = threadIdx.x;
-    constexpr int TKm = 16, STR = 144;
-    double *As = sm, *Bs = sm + 2 * TKm * STR;
+    // (arguments of a function that is not inlined arrive in vector registers and as generic pointers: say that they are uniform and
+    // that C is global memory -- flat stores would also count on the LDS counter the k loop waits on)
+    ld = __builtin_amdgcn_readfirstlane(ld);
+    K = __builtin_amdgcn_readfirstlane(K);
+    quarter = __builtin_amdgcn_readfirstlane(quarter);
+    diag = __builtin_amdgcn_readfirstlane((int)diag) != 0;
+    typedef __attribute__((address_space(1))) double gdouble;
+    gdouble *const Cg = (gdouble *)Cp;
+    constexpr int TKm = 16, STR = 144, NST = 4;
+    double *As = sm, *Bs = sm + NST * TKm * STR;
     const int lane = tid & 63, wave = tid >> 6, fr = lane & 15, fk = lane >> 4;
     const double *Asrc = Ap + lane * 2 + (size_t)wave * ld, *Bsrc = Bp + lane * 2 + (size_t)wave * ld;
-    auto stage = [&](int buf, int kt) {
+    auto stage = [&](int kt) {      // k-slice kt into ring slot kt % NST: four LDS-DMA instructions per wave
         const size_t koff = (size_t)kt * TKm;
+        const int buf = kt & (NST - 1);
 #pragma unroll
         for (int q = 0; q < TKm / 8; ++q) {
             __builtin_amdgcn_global_load_lds(Asrc + (koff + 8 * q) * ld, As + (buf * TKm + wave + 8 * q) * STR, 16, 0, 0);
@@ -566,34 +580,65 @@ __device__ __noinline__ void mega_gemm_tile(const double *__restrict__ Ap, const
         }
     };
     const int KT = K / TKm;
+    // slice kt is in LDS for everybody: this wave's own share has landed (the two slices requested after it may still be in flight:
+    // vmcnt counts in issue order), its reads of the slice before are done, then the barrier; the slot of slice kt - 1 is free after it
+    auto arrive = [&](int kt) {
+        if (kt + 2 < KT) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        else if (kt + 1 < KT) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kt + 3 < KT) stage(kt + 3);
+    };
+    stage(0);
+    if (KT > 1) stage(1);
+    if (KT > 2) stage(2);
     if (quarter >= 0) {
         // A quarter is on the chain's way (the next diagonal block's tile): all eight waves share its 64 x 64 -- wave w: rows 16 (w & 3),
         // columns 32 (w >> 2), two accumulators -- so its k loop is a quarter of a full tile's instead of the same length on two waves.
         // Same products in the same k order per element as the full tile.
         const int wr = 64 * (quarter & 1) + 16 * (wave & 3), wc = 64 * (quarter >> 1) + 32 * (wave >> 2);
         double4_t acc[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
-        stage(0, 0);
-        __syncthreads();
         for (int kt = 0; kt < KT; ++kt) {
-            const int cur = kt & 1;
-            if (kt + 1 < KT) stage(cur ^ 1, kt + 1);
+            arrive(kt);
+            const int cur = kt & (NST - 1);
             const double *Ac = As + cur * TKm * STR + wr + fr, *Bc = Bs + cur * TKm * STR + wc + fr;
+            // fragments one k-group ahead of the matrix cores (two waves per SIMD, in step with each other: nothing else hides an LDS read)
+            double af = Ac[fk * STR], bf0 = Bc[fk * STR], bf1 = Bc[fk * STR + 16];
 #pragma unroll
             for (int ks = 0; ks < TKm / 4; ++ks) {
-                const double af = Ac[(ks * 4 + fk) * STR];
-#pragma unroll
-                for (int u = 0; u < 2; ++u) acc[u] = MFMA(Bc[(ks * 4 + fk) * STR + u * 16], af, acc[u]);
+                const double a0 = af, b0 = bf0, b1 = bf1;
+                if (ks + 1 < TKm / 4) {
+                    af = Ac[((ks + 1) * 4 + fk) * STR];
+                    bf0 = Bc[((ks + 1) * 4 + fk) * STR];
+                    bf1 = Bc[((ks + 1) * 4 + fk) * STR + 16];
+                }
+                acc[0] = MFMA(b0, a0, acc[0]);
+                acc[1] = MFMA(b1, a0, acc[1]);
             }
-            __syncthreads();
         }
         const int m = wr + fr;
         double cv[2][4];
+        if (!diag) {
+            // off the diagonal nothing is masked: eight loads in flight together, eight stores nobody waits for.  (With the mask
+            // in the way -- one exec-masked block per element -- the compiler cannot count what is outstanding and puts
+            // `s_waitcnt vmcnt(0)` in front of every store: each store then waits for the acknowledgement of the one before it.)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cv[nt][r] = Cg[m + (size_t)(wc + nt * 16 + fk + 4 * r) * ld];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Cg[m + (size_t)(wc + nt * 16 + fk + 4 * r) * ld] = fma(1.0, cv[nt][r], -1.0 * acc[nt][r]);
+            return;
+        }
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int n = wc + nt * 16 + fk + 4 * r;
-                cv[nt][r] = (diag && m < n) ? 0.0 : Cp[m + (size_t)n * ld];
+                cv[nt][r] = (m < n) ? 0.0 : Cg[m + (size_t)n * ld];
             }
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
@@ -601,7 +646,7 @@ __device__ __noinline__ void mega_gemm_tile(const double *__restrict__ Ap, const
             for (int r = 0; r < 4; ++r) {
                 const int n = wc + nt * 16 + fk + 4 * r;
                 const double v = fma(1.0, cv[nt][r], -1.0 * acc[nt][r]);
-                if (!(diag && m < n)) Cp[m + (size_t)n * ld] = v;
+                if (!(m < n)) Cg[m + (size_t)n * ld] = v;
             }
         return;
     }
@@ -611,27 +656,52 @@ __device__ __noinline__ void mega_gemm_tile(const double *__restrict__ Ap, const
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
-    stage(0, 0);
-    __syncthreads();
     for (int kt = 0; kt < KT; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < KT) stage(cur ^ 1, kt + 1);
+        arrive(kt);
+        const int cur = kt & (NST - 1);
         const double *Ac = As + cur * TKm * STR + wm + fr, *Bc = Bs + cur * TKm * STR + wn + fr;
+        double afn[4], bfn[2];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) afn[u] = Ac[fk * STR + u * 16];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) bfn[u] = Bc[fk * STR + u * 16];
 #pragma unroll
         for (int ks = 0; ks < TKm / 4; ++ks) {
             double af[4], bf[2];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) af[u] = Ac[(ks * 4 + fk) * STR + u * 16];
+            for (int u = 0; u < 4; ++u) af[u] = afn[u];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) bf[u] = Bc[(ks * 4 + fk) * STR + u * 16];
+            for (int u = 0; u < 2; ++u) bf[u] = bfn[u];
+            if (ks + 1 < TKm / 4) {      // the next k-group's fragments are on their way while these sixteen products issue
+#pragma unroll
+                for (int u = 0; u < 4; ++u) afn[u] = Ac[((ks + 1) * 4 + fk) * STR + u * 16];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) bfn[u] = Bc[((ks + 1) * 4 + fk) * STR + u * 16];
+            }
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = MFMA(bf[nt], af[mt], acc[nt][mt]);
         }
-        __syncthreads();
     }
     // acc[nt][mt][r] = sum over k for (m = wm + 16 mt + fr, n = wn + 16 nt + fk + 4 r): C <- 1.0 * C + (-1.0) * acc, as gemm_nt_f64_kernel
+    if (!diag) {
+        // unmasked (see the quarter's epilogue): per column half sixteen loads together, then sixteen stores
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            double cv[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) cv[r][mt] = Cg[(wm + mt * 16 + fr) + (size_t)(wn + nt * 16 + fk + 4 * r) * ld];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+                    Cg[(wm + mt * 16 + fr) + (size_t)(wn + nt * 16 + fk + 4 * r) * ld] = fma(1.0, cv[r][mt], -1.0 * acc[nt][mt][r]);
+        }
+        return;
+    }
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         double cv[4][4];
@@ -641,7 +711,7 @@ __device__ __noinline__ void mega_gemm_tile(const double *__restrict__ Ap, const
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
                 const int m = wm + mt * 16 + fr;
-                cv[r][mt] = (diag && m < n) ? 0.0 : Cp[m + (size_t)n * ld];
+                cv[r][mt] = (m < n) ? 0.0 : Cg[m + (size_t)n * ld];
             }
         }
 #pragma unroll
@@ -651,7 +721,7 @@ __device__ __noinline__ void mega_gemm_tile(const double *__restrict__ Ap, const
             for (int mt = 0; mt < 4; ++mt) {
                 const int m = wm + mt * 16 + fr;
                 const double v = fma(1.0, cv[r][mt], -1.0 * acc[nt][mt][r]);
-                if (!(diag && m < n)) Cp[m + (size_t)n * ld] = v;
+                if (!(m < n)) Cg[m + (size_t)n * ld] = v;
             }
         }
     }
@@ -895,7 +965,7 @@ static constexpr int POTRF_LDS = (NB * PLS + 256 + 8) * (int)sizeof(double);
 static constexpr int TRSM_LDS = NB * XS * (int)sizeof(double);
 static constexpr int STEP_LDS = (NB * LS1 + 8 * 256 + NB + 16) * (int)sizeof(double);
 static constexpr int LINK_LDS = NB * LKS * (int)sizeof(double);
-static constexpr int MEGA_LDS = POTRF_LDS > LINK_LDS ? POTRF_LDS : LINK_LDS;     // the diagonal block's image / the 128-row strip / 72 KB of GEMM staging
+static constexpr int MEGA_LDS = POTRF_LDS > LINK_LDS ? POTRF_LDS : LINK_LDS;     // the diagonal block's image / the 128-row strip / 144 KB of GEMM staging (ring of four k-slices)
 
 int gpk_init_diag_kernels() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(potrf_diag128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, POTRF_LDS);

@@ -17,6 +17,7 @@
 // bank-conflict free.  The MFMA is issued with the B-fragment as srcA and the A-fragment as srcB
 // so each lane's accumulator holds 4 consecutive-n values at one m: stores are 128-B row segments
 // of column-major C.
+#include <type_traits>
 #include "gpcore_internal.h"
 #include <algorithm>
 
@@ -185,38 +186,48 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void gemm_nt_f64_kernel(int M, int
     // epilogue: acc[nt][mt][r] = D[n = wn + nt*16 + fk + 4r][m = wm + mt*16 + fr].
     // C is read in batches of 16 independent loads per 16-column group, then written: a load/wait/store chain per
     // element (what a naive `v += beta * *cp` compiles to) serialises 64 memory round trips per tile.
+    // Lower-trapezoid launches: only the tiles ON the diagonal mask anything, and the two cases are separate code.  With the mask's test
+    // around every load and store of every tile (`(diag_tile && m < n) ? 0.0 : load`, one exec-masked block per element) the compiler
+    // cannot count what is outstanding and puts `s_waitcnt vmcnt(0)` in front of each store: every store then waits for the
+    // acknowledgement of the one before it, 32 round trips per tile on every tile of every trailing update (found in round 4 in the
+    // single-launch factorisation's copy of this loop; rounds 1-3 ran with it).
     const bool diag_tile = LOWER && (bi == bj);
     double rsq[4] = {0.0, 0.0, 0.0, 0.0}, rdt[4] = {0.0, 0.0, 0.0, 0.0};   // RR: per (mt) row partial sums of this lane
+    auto epilogue = [&](auto masked_t) {
+        constexpr bool MASKED = decltype(masked_t)::value;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        double cv[4][4];
-        if (HAS_BETA) {
+        for (int nt = 0; nt < NT; ++nt) {
+            double cv[4][4];
+            if (HAS_BETA) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = col0 + wn + nt * 16 + fk + 4 * r;
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) {
+                        const int m = row0 + wm + mt * 16 + fr;
+                        cv[r][mt] = (MASKED && m < n) ? 0.0 : Cin[m + (size_t)n * ldcin];
+                    }
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int n = col0 + wn + nt * 16 + fk + 4 * r;
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) {
                     const int m = row0 + wm + mt * 16 + fr;
-                    cv[r][mt] = (diag_tile && m < n) ? 0.0 : Cin[m + (size_t)n * ldcin];
+                    double v = alpha * acc[nt][mt][r];
+                    if (HAS_BETA) v = fma(beta, cv[r][mt], v);
+                    if (!(MASKED && m < n)) C[m + (size_t)n * ldc] = v;
+                    if (RR) {
+                        rsq[mt] = fma(v, v, rsq[mt]);
+                        if (rr.dots) rdt[mt] = fma(v, rr.tvec[n], rdt[mt]);
+                    }
                 }
             }
         }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int n = col0 + wn + nt * 16 + fk + 4 * r;
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const int m = row0 + wm + mt * 16 + fr;
-                double v = alpha * acc[nt][mt][r];
-                if (HAS_BETA) v = fma(beta, cv[r][mt], v);
-                if (!(diag_tile && m < n)) C[m + (size_t)n * ldc] = v;
-                if (RR) {
-                    rsq[mt] = fma(v, v, rsq[mt]);
-                    if (rr.dots) rdt[mt] = fma(v, rr.tvec[n], rdt[mt]);
-                }
-            }
-        }
-    }
+    };
+    if (diag_tile) epilogue(std::true_type{});
+    else epilogue(std::false_type{});
     if (urgent) {
         __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's stores are acknowledged
         __syncthreads();
@@ -335,37 +346,42 @@ __global__ __launch_bounds__(WV * 64, 1) void gemm_fused_kernel(int M, int N, in
     }
     const bool diag = LOWER && (row0 < col0 + TN);   // the tile touches or crosses the diagonal
     double rsq[4] = {0.0, 0.0, 0.0, 0.0}, rdt[4] = {0.0, 0.0, 0.0, 0.0};
+    auto epilogue = [&](auto masked_t) {      // masked and unmasked tiles as separate code: see gemm_nt_f64_kernel
+        constexpr bool MASKED = decltype(masked_t)::value;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        double cv[4][4];
-        if (HAS_BETA) {
+        for (int nt = 0; nt < NT; ++nt) {
+            double cv[4][4];
+            if (HAS_BETA) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = col0 + wn + nt * 16 + fk + 4 * r;
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) {
+                        const int m = row0 + wm + mt * 16 + fr;
+                        cv[r][mt] = (MASKED && m < n) ? 0.0 : C[m + (size_t)n * ldc];
+                    }
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int n = col0 + wn + nt * 16 + fk + 4 * r;
+                const double tn = (RR && rr.dots) ? rr.tvec[n] : 0.0;
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) {
                     const int m = row0 + wm + mt * 16 + fr;
-                    cv[r][mt] = (diag && m < n) ? 0.0 : C[m + (size_t)n * ldc];
+                    double v = alpha * acc[nt][mt][r];
+                    if (HAS_BETA) v = fma(beta, cv[r][mt], v);
+                    if (!(MASKED && m < n)) C[m + (size_t)n * ldc] = v;
+                    if (RR) {
+                        rsq[mt] = fma(v, v, rsq[mt]);
+                        rdt[mt] = fma(v, tn, rdt[mt]);
+                    }
                 }
             }
         }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int n = col0 + wn + nt * 16 + fk + 4 * r;
-            const double tn = (RR && rr.dots) ? rr.tvec[n] : 0.0;
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const int m = row0 + wm + mt * 16 + fr;
-                double v = alpha * acc[nt][mt][r];
-                if (HAS_BETA) v = fma(beta, cv[r][mt], v);
-                if (!(diag && m < n)) C[m + (size_t)n * ldc] = v;
-                if (RR) {
-                    rsq[mt] = fma(v, v, rsq[mt]);
-                    rdt[mt] = fma(v, tn, rdt[mt]);
-                }
-            }
-        }
-    }
+    };
+    if (diag) epilogue(std::true_type{});
+    else epilogue(std::false_type{});
     if (RR) {
         constexpr int NG = WV / 4;   // column groups of waves
         double *red = fsm;   // [2][NG][FM]
@@ -452,22 +468,27 @@ __global__ __launch_bounds__(256) void gemm_k128_kernel(int M, int N, int K, con
         }
     }
     const bool diag_tile = LOWER && (bi == bj);
+    auto epilogue = [&](auto masked_t) {      // masked and unmasked tiles as separate code: see gemm_nt_f64_kernel
+        constexpr bool MASKED = decltype(masked_t)::value;
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
+        for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            double cv[4];
+            for (int mt = 0; mt < 2; ++mt) {
+                double cv[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = i0 + wi + 16 * mt + fr, n = j0 + wj + 16 * nt + fk + 4 * r;
-                cv[r] = (diag_tile && m < n) ? 0.0 : C[m + (size_t)n * ldc];
+                for (int r = 0; r < 4; ++r) {
+                    const int m = i0 + wi + 16 * mt + fr, n = j0 + wj + 16 * nt + fk + 4 * r;
+                    cv[r] = (MASKED && m < n) ? 0.0 : C[m + (size_t)n * ldc];
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = i0 + wi + 16 * mt + fr, n = j0 + wj + 16 * nt + fk + 4 * r;
+                    if (!(MASKED && m < n)) C[m + (size_t)n * ldc] = cv[r] - acc[nt][mt][r];
+                }
             }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = i0 + wi + 16 * mt + fr, n = j0 + wj + 16 * nt + fk + 4 * r;
-                if (!(diag_tile && m < n)) C[m + (size_t)n * ldc] = cv[r] - acc[nt][mt][r];
-            }
-        }
+    };
+    if (diag_tile) epilogue(std::true_type{});
+    else epilogue(std::false_type{});
 }
 
 constexpr int FUSED_LDS = (2 * TK * FSTRIDE + 2 * TK * LDS_STRIDE) * (int)sizeof(double);
