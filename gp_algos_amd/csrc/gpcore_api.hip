@@ -37,7 +37,7 @@ struct ws_slot { void *p = nullptr; size_t bytes = 0; unsigned long long tag = 0
 struct mega_task { int type, k0, kb, i, j, q, dep[10]; };
 struct mega_plan { int np = 0, extra = 0, out_blocks = 0, workers = 0; double model_us = 0.0; std::vector<mega_task> tasks; };
 // the persistent-launch factorisation's state: the plan of the shape used last, its copy on the device, the flags
-struct mega_state { mega_plan plan; int *d_tasks = nullptr, *d_done = nullptr, *d_ctl = nullptr; int cap = 0, epoch = 0; };
+struct mega_state { mega_plan plan; int *d_tasks = nullptr, *d_done = nullptr, *d_ctl = nullptr; double *d_sums = nullptr; int cap = 0, epoch = 0, sums_cap = 0; };
 
 struct ctx_ext { ws_slot ws[WS_COUNT]; std::vector<gp_ctx *> children; mega_state mega; };
 
@@ -170,8 +170,12 @@ bool chol_mega_plan(int np, int extra, int out_blocks, int workers, mega_plan &p
     // last writers of a tile: the task(s) whose result the next reader / writer of tile (i, j) must wait for (up to 4 quarters)
     std::vector<std::vector<int>> last((size_t)nrow * nb);
     auto tile = [&](int i, int j) -> std::vector<int> & { return last[(size_t)i * nb + j]; };
-    // us per task on one CU, from tools/mega_trace.py (profiles/r04_g_mega_trace.log): body + publish
-    const double c_potrf = 25.3, c_trsm = 21.7, c_k128 = 28.4, c_k512 = 81.0, c_q128 = 9.0, c_q512 = 30.0, c_link = 20.0;
+    // us per task on one CU, from tools/mega_trace.py (profiles/r04_q_mega_trace_boundary_sums.log): body + publish
+    // (the list is not sensitive to them: with every cost 10 % lower or higher, or the link at 45 instead of 30, n = 8192 refits in
+    // 4.80-4.90 ms, profiles/r04_r_fit_mega_cost_model_sweep.log)
+    double c_potrf = 27.5, c_trsm = 20.8, c_k128 = 25.1, c_k512 = 77.7, c_q128 = 9.0, c_q512 = 27.8, c_link = 30.0;
+    if (const char *e = getenv("GPCORE_MEGA_COSTS"))      // lab: "potrf,trsm,k128,k512,q128,q512,link" -- what-if runs of the model (gp_chol_plan_info)
+        sscanf(e, "%lf,%lf,%lf,%lf,%lf,%lf,%lf", &c_potrf, &c_trsm, &c_k128, &c_k512, &c_q128, &c_q512, &c_link);
     auto add = [&](int type, int k0, int kb, int i, int j, int q, double cost, std::vector<int> deps) {
         node nd;
         nd.t = mega_task{type, k0, kb, i, j, q, {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1}};
@@ -183,22 +187,28 @@ bool chol_mega_plan(int np, int extra, int out_blocks, int workers, mega_plan &p
         return (int)g.size() - 1;
     };
     std::vector<int> pre_x;       // writers of tile (k+1, k) before its rows are solved: what the fused task of block k+1 waits for
+    std::vector<int> early;       // the type-5 quarters of the next panel's first diagonal tile
     for (int c0 = 0; c0 < nb; c0 += out_blocks) {
         const int c1 = std::min(nb, c0 + out_blocks);
         for (int k = c0; k < c1; ++k) {
-            if (k == c0) potrf_of[k] = add(0, k, 1, k, k, -1, c_potrf, tile(k, k));
+            if (k == 0) potrf_of[k] = add(0, k, 1, k, k, -1, c_potrf, tile(k, k));
             else {
-                // inside the panel: the link to block k-1 (solve of rows k of block column k-1, last in-panel update of tile (k, k)) is the
-                // prologue of the diagonal block's task; the place holder made in step k-1 stands for the solved rows
+                // every later block: the link to block k-1 (solve of rows k of block column k-1, the update of tile (k, k) that those rows
+                // complete) is the prologue of the diagonal block's task; the place holder made in step k-1 stands for the solved rows.
+                // Inside a panel that update is the in-panel one (K = 128, summed from zero).  For a panel's FIRST block it is the previous
+                // panel's outer update of the tile: its earlier block columns were summed ahead of time by the type-5 quarters made in
+                // step k-2 (slot = the panel's number), the task continues that sum (field j = the slot).
                 std::vector<int> d = tile(k, k);
                 d.insert(d.end(), pre_x.begin(), pre_x.end());
                 d.push_back(potrf_of[k - 1]);
-                potrf_of[k] = add(4, k, 1, k, k, trsm_of[(size_t)(k - 1) * nrow + k], c_link + c_potrf, d);
+                int slot = -1;
+                if (k == c0 && !early.empty()) { slot = c0 / out_blocks; d.insert(d.end(), early.begin(), early.end()); early.clear(); }
+                potrf_of[k] = add(4, k, 1, k, slot, trsm_of[(size_t)(k - 1) * nrow + k], c_link + c_potrf, d);
                 g[trsm_of[(size_t)(k - 1) * nrow + k]].t.kb = potrf_of[k];      // the place holder remembers who announces it
             }
             tile(k, k) = {potrf_of[k]};
             for (int i = k + 1; i < nrow; ++i) {
-                if (i == k + 1 && i < c1) {
+                if (i == k + 1 && i < nb) {
                     pre_x = tile(i, k);
                     trsm_of[(size_t)k * nrow + i] = add(3, k, -1, i, k, -1, -1.0, {});
                     tile(i, k) = {trsm_of[(size_t)k * nrow + i]};
@@ -208,6 +218,15 @@ bool chol_mega_plan(int np, int extra, int out_blocks, int workers, mega_plan &p
                 d.push_back(potrf_of[k]);
                 trsm_of[(size_t)k * nrow + i] = add(1, k, 1, i, k, -1, c_trsm, d);
                 tile(i, k) = {trsm_of[(size_t)k * nrow + i]};
+            }
+            if (k == c1 - 2 && c1 < nb) {
+                // the next panel's first diagonal tile: all but the last block column of ITS outer update can be summed now (rows c1 of
+                // the block columns c0 .. c1-2 are solved), into the panel's scratch tile -- three quarters, (0, 1) is above the diagonal
+                const int kb = c1 - 1 - c0;
+                std::vector<int> d;
+                for (int kk = c0; kk <= k; ++kk) d.push_back(trsm_of[(size_t)kk * nrow + c1]);
+                for (int q = 0; q < 4; ++q)
+                    if (q != 2) early.push_back(add(5, c0, kb, c1, c1 / out_blocks, q, c_q128 + (c_q512 - c_q128) * (kb - 1) / 3.0, d));
             }
             for (int j = k + 1; j < c1; ++j)
                 for (int i = j; i < nrow; ++i) {
@@ -225,6 +244,7 @@ bool chol_mega_plan(int np, int extra, int out_blocks, int workers, mega_plan &p
                 d.push_back(trsm_of[(size_t)(c1 - 1) * nrow + j]);
                 const int kb = c1 - c0;
                 const double cost = c_k128 + (c_k512 - c_k128) * (kb - 1) / 3.0, qcost = c_q128 + (c_q512 - c_q128) * (kb - 1) / 3.0;
+                if (i == c1 && j == c1) continue;      // the next panel's first diagonal tile: type-5 quarters + that block's fused task
                 if (i < c1 + out_blocks && j < c1 + out_blocks && i < nb) {      // the next outer panel's diagonal block: quarters
                     std::vector<int> w;
                     for (int q = 0; q < 4; ++q)
@@ -326,6 +346,14 @@ bool chol_mega_run(gp_ctx *ctx, double *A, int np, int lda, double *dinv, int ex
             ms.cap = n;
         }
         if (!ms.d_ctl && (hipMalloc(&ms.d_ctl, sizeof(int) * 4) != hipSuccess || hipMemset(ms.d_ctl, 0, sizeof(int) * 4) != hipSuccess)) { (void)hipGetLastError(); return false; }
+        const int slots = np / GP_NB / out_blocks + 1;      // one scratch tile per outer panel: the started sum of its first diagonal tile
+        if (slots > ms.sums_cap) {
+            if (hipStreamSynchronize(ctx->stream) != hipSuccess) return false;
+            if (ms.d_sums) (void)hipFree(ms.d_sums);
+            ms.d_sums = nullptr, ms.sums_cap = 0;
+            if (hipMalloc(&ms.d_sums, sizeof(double) * GP_NB * GP_NB * (size_t)slots) != hipSuccess) { (void)hipGetLastError(); return false; }
+            ms.sums_cap = slots;
+        }
         // (synchronous copy: the previous launch may still be reading the old list)
         if (hipStreamSynchronize(ctx->stream) != hipSuccess) return false;
         if (hipMemcpy(ms.d_tasks, pl.tasks.data(), sizeof(mega_task) * (size_t)n, hipMemcpyHostToDevice) != hipSuccess) return false;
@@ -341,7 +369,7 @@ bool chol_mega_run(gp_ctx *ctx, double *A, int np, int lda, double *dinv, int ex
     if (trace && hipMalloc(&d_st, sizeof(unsigned long long) * 4 * (size_t)n) != hipSuccess) { (void)hipGetLastError(); d_st = nullptr; }
     if (d_st) (void)hipMemsetAsync(d_st, 0, sizeof(unsigned long long) * 4 * (size_t)n, ctx->stream);
     gp_prof_begin(ctx, GP_PROF_SYRK);
-    gpk_chol_mega(ctx->stream, workers, A, lda, dinv, ctx->d_info, ms.d_tasks, n, ms.d_done, ms.d_ctl, ms.epoch, ms.d_ctl + 1, d_st);
+    gpk_chol_mega(ctx->stream, workers, A, lda, dinv, ctx->d_info, ms.d_tasks, n, ms.d_done, ms.d_ctl, ms.epoch, ms.d_ctl + 1, ms.d_sums, d_st);
     gp_prof_end(ctx, GP_PROF_SYRK, (double)np * np * np / 3.0);
     if (d_st) {
         std::vector<unsigned long long> h(4 * (size_t)n);
@@ -380,14 +408,14 @@ void chol_blocked(gp_ctx *ctx, double *A, int np, int lda, double *dinv, int ext
     const int outer_env = gp_env_blocks("GPCORE_OUTER");
     const int OUTER = outer_env ? outer_env : (np > 16384 ? 2 * GP_OUTER : GP_OUTER);
     {   // One persistent launch instead of ~250 (chol_mega_kernel): single factorisations that would run with look-ahead, where it wins --
-        // refit ms, launch-per-step / single launch (profiles/r04_h_fit_mega.log): n = 4096 1.97 / 2.05, 5120 2.73 / 2.74, 6144 3.58 / 3.28,
-        // 7168 4.60 / 3.94, 8192 5.94 / 4.94, 10240 9.49 / 8.40, 12288 14.49 / 13.85, 14336 21.39 / 21.24, 16384 30.43 / 31.09: below ~5600
-        // rows the chain is the same length either way, above ~14000 the factorisation is bound by GEMM throughput and one workgroup per CU
-        // on 128 x 128 tiles (78 us per K = 512 tile) is no faster than two.  GPCORE_CHOL_MEGA = 0 / 1 forces (read per call: the tests
+        // refit ms, launch-per-step / single launch (profiles/r04_final_fit_mega.log): n = 4096 1.92 / 1.98, 5120 2.70 / 2.55, 6144 3.42 / 3.20,
+        // 8192 5.74 / 4.81, 10240 9.17 / 8.17, 12288 14.27 / 13.45, 14336 21.30 / 20.55, 16384 30.05 / 30.03: below ~5000 rows the chain
+        // is the same length either way, above ~14000 the factorisation is bound by GEMM throughput and one workgroup per CU on
+        // 128 x 128 tiles (77 us per K = 512 tile) is no faster than two.  GPCORE_CHOL_MEGA = 0 / 1 forces (read per call: the tests
         // run every form in one process).
         const char *me = getenv("GPCORE_CHOL_MEGA");
         const bool forced = me && atoi(me) != 0, off = me && atoi(me) == 0;
-        const bool by_size = np >= 5632 && np <= 14336;
+        const bool by_size = np >= 5120 && np <= 14336;
         if (!off && (forced || by_size) && lookahead && info == ctx->d_info && np >= 4 * OUTER && extra <= GP_NB &&
             chol_mega_run(ctx, A, np, lda, dinv, extra, OUTER / GP_NB)) return;
     }
@@ -881,6 +909,7 @@ void gp_ctx_destroy(gp_ctx *ctx) {
     if (x->mega.d_tasks) (void)hipFree(x->mega.d_tasks);
     if (x->mega.d_done) (void)hipFree(x->mega.d_done);
     if (x->mega.d_ctl) (void)hipFree(x->mega.d_ctl);
+    if (x->mega.d_sums) (void)hipFree(x->mega.d_sums);
     if (ctx->d_scalars) (void)hipFree(ctx->d_scalars);
     if (ctx->d_info) (void)hipFree(ctx->d_info);
     if (ctx->ev_a) (void)hipEventDestroy(ctx->ev_a);
@@ -958,17 +987,28 @@ gp_status gp_chol_plan_info(int n, int extra_rows, int workgroups, int *ntasks, 
     if (!chol_mega_plan(n, extra_rows, ob, workgroups, pl)) return GP_EINVAL;
     // independent check of the list: replay it and count, per tile, the updates in the order the two-level scheme applies them
     const int nb = n / GP_NB, nrow = (n + extra_rows) / GP_NB;
-    std::vector<int> upd((size_t)nrow * nb, 0), quarters((size_t)nrow * nb, 0), solved((size_t)nrow * nb, 0), fact(nb, 0);
+    std::vector<int> upd((size_t)nrow * nb, 0), quarters((size_t)nrow * nb, 0), solved((size_t)nrow * nb, 0), fact(nb, 0), started(nb, 0);
     auto expected = [&](int i, int j) { const int J = j / ob; return J + (j - J * ob); };      // outer updates of the panels before j's, then the in-panel ones
     for (size_t p2 = 0; p2 < pl.tasks.size(); ++p2) {
         const mega_task &t = pl.tasks[p2];
         for (int d = 0; d < 10; ++d) if (t.dep[d] >= (int)p2) return GP_EINVAL;
         if (t.type == 3) continue;                       // a place holder: announced by the fused task that names it
         if (t.type == 0) { if (upd[(size_t)t.k0 * nb + t.k0] != expected(t.k0, t.k0) || fact[t.k0]++) return GP_EINVAL; }
+        else if (t.type == 5) {
+            // a quarter of the started sum of a panel's first diagonal tile: rows t.i of the previous panel's block columns but the last,
+            // all solved; three quarters per slot, each once
+            const int k = t.i;
+            if (k % ob != 0 || k == 0 || t.j != k / ob || t.k0 != k - ob || t.kb != ob - 1 || t.q < 0 || t.q > 3 || t.q == 2 || fact[k]) return GP_EINVAL;
+            for (int kk = t.k0; kk < t.k0 + t.kb; ++kk) if (!solved[(size_t)k * nb + kk]) return GP_EINVAL;
+            if (started[k] & (1 << t.q)) return GP_EINVAL;
+            started[k] |= 1 << t.q;
+        }
         else if (t.type == 4) {
-            // link + diagonal block: solves rows k of block column k-1 (after all ITS updates), applies the last in-panel update to tile (k, k)
+            // link + diagonal block: solves rows k of block column k-1 (after all ITS updates) and completes the update of tile (k, k) those
+            // rows belong to: the in-panel one, or -- first block of a panel -- the previous panel's outer one, continued from its slot
             const int k = t.k0;
-            if (k == 0 || k % ob == 0 || !fact[k - 1] || upd[(size_t)k * nb + (k - 1)] != expected(k, k - 1) || solved[(size_t)k * nb + (k - 1)]++) return GP_EINVAL;
+            if (k == 0 || !fact[k - 1] || upd[(size_t)k * nb + (k - 1)] != expected(k, k - 1) || solved[(size_t)k * nb + (k - 1)]++) return GP_EINVAL;
+            if (k % ob == 0 && ob > 1 ? (t.j != k / ob || started[k] != 0xB) : (t.j != -1)) return GP_EINVAL;
             if (t.q < 0 || t.q >= (int)pl.tasks.size() || pl.tasks[t.q].type != 3 || (size_t)t.q <= p2) return GP_EINVAL;   // its place holder follows it in the list
             if (++upd[(size_t)k * nb + k] != expected(k, k) || fact[k]++) return GP_EINVAL;
         }

@@ -164,7 +164,7 @@ int gpk_init_gemm_kernels();
 void gpk_potrf_diag128(hipStream_t s, double *A, int lda, double *dinv_k, int *d_info, int base, gp_batch bt = gp_batch());
 // the whole two-level factorisation of one matrix as one persistent launch over a task list (16 ints per task: kernels_diag.hip chol_task)
 void gpk_chol_mega(hipStream_t s, int num_cu, double *A, int lda, double *dinv, int *d_info, const int *tasks, int ntasks, int *done, int *counter,
-                   int epoch, int *err, unsigned long long *stamps = nullptr);   // stamps: lab, 4 x 8 bytes per task   // strides: A, dinv; d_info + 1 per problem
+                   int epoch, int *err, double *sums, unsigned long long *stamps = nullptr);   // sums: one NB x NB scratch tile per outer panel   // stamps: lab, 4 x 8 bytes per task   // strides: A, dinv; d_info + 1 per problem
 // optional fused row reductions: sumsq[p] += sum_c X(p,c)^2 ; dots[p] += sum_c X(p,c) tvec[c]
 // EP: the 128 rows of the delayed columns that belong to the next site block (X <- X Lmat^-T in place, X2 = X diag(cs2), dots += X tvec)
 // and the 128 x 128 lower tile D -= X2 X^T the next block kernel reads, one workgroup (kernels_diag.hip)

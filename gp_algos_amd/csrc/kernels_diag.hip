@@ -540,7 +540,7 @@ __global__ __launch_bounds__(64) void tile_inverse_kernel(const double *__restri
 // host), so everything a claimed task waits for was claimed earlier by a workgroup that is resident and will finish.
 // The ORDER of the list is a list schedule computed on the host from a cost model (critical path first: chol_mega_plan): claimed in
 // that order the dependencies are mostly met on arrival, and what waits is what the model would have idle anyway.
-struct chol_task { int type, k0, kb, i, j, q, dep[10]; };   // 64 bytes; type 0 POTRF (k0), 1 TRSM (k0, i), 2 UPD, 3 a place holder, 4 link + POTRF (k0; q = the place holder it announces)
+struct chol_task { int type, k0, kb, i, j, q, dep[10]; };   // 64 bytes; type 0 POTRF (k0), 1 TRSM (k0, i), 2 UPD, 3 a place holder, 4 link + POTRF (k0; q = the place holder it announces, j = slot of the started sum or -1), 5 quarter q of a started sum (rows i, K = 128 kb from block column k0, into slot j)
 constexpr int MEGA_THREADS = 512;
 
 // tile (128 x 128 at Cp) -= A (128 x K at Ap) B (128 x K at Bp)^T, all with leading dimension ld: gemm_nt_f64_kernel's products (8 waves
@@ -551,8 +551,10 @@ constexpr int MEGA_THREADS = 512;
 // two neighbours on the same XCD: the operands come from HBM, not L2 (PMC: 12.9 GB per factorisation, 24 x the matrix,
 // profiles/r04_final pmc_c2 first pass), and with the next slice requested only one slice ahead every k step waited for memory --
 // 2.46 us per step against 1.7 us of matrix-core time, a quarter (0.2 us of matrix-core time per step) 0.9 us.
+// quarter q + 4: the quarter's sum of products alone, written (all 64 x 64 elements, nothing read) to Cp with leading dimension ldc --
+// a STARTED sum that mega_potrf_link continues (the first block of an outer panel, below).
 __device__ __noinline__ void mega_gemm_tile(const double *__restrict__ Ap, const double *__restrict__ Bp, double *__restrict__ Cp,
-                                            int ld, int K, bool diag, int quarter) {
+                                            int ld, int ldc, int K, bool diag, int quarter) {
     // (each task body is a function of its own: inlined into one kernel the three of them need more than the 256 registers a wave of
     // a 512-thread workgroup can have, and the diagonal block's serial chain is the last place for scratch traffic; the dynamic LDS is
     // named here again rather than passed, so that the compiler keeps LDS addressing)
@@ -561,8 +563,11 @@ __device__ __noinline__ void mega_gemm_tile(const double *__restrict__ Ap, const
     // (arguments of a function that is not inlined arrive in vector registers and as generic pointers: say that they are uniform and
     // that C is global memory -- flat stores would also count on the LDS counter the k loop waits on)
     ld = __builtin_amdgcn_readfirstlane(ld);
+    ldc = __builtin_amdgcn_readfirstlane(ldc);
     K = __builtin_amdgcn_readfirstlane(K);
     quarter = __builtin_amdgcn_readfirstlane(quarter);
+    const bool raw = quarter >= 4;
+    if (raw) quarter -= 4;
     diag = __builtin_amdgcn_readfirstlane((int)diag) != 0;
     typedef __attribute__((address_space(1))) double gdouble;
     gdouble *const Cg = (gdouble *)Cp;
@@ -618,6 +623,13 @@ __device__ __noinline__ void mega_gemm_tile(const double *__restrict__ Ap, const
             }
         }
         const int m = wr + fr;
+        if (raw) {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Cg[m + (size_t)(wc + nt * 16 + fk + 4 * r) * ldc] = acc[nt][r];
+            return;
+        }
         double cv[2][4];
         if (!diag) {
             // off the diagonal nothing is masked: eight loads in flight together, eight stores nobody waits for.  (With the mask
@@ -626,11 +638,11 @@ __device__ __noinline__ void mega_gemm_tile(const double *__restrict__ Ap, const
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) cv[nt][r] = Cg[m + (size_t)(wc + nt * 16 + fk + 4 * r) * ld];
+                for (int r = 0; r < 4; ++r) cv[nt][r] = Cg[m + (size_t)(wc + nt * 16 + fk + 4 * r) * ldc];
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) Cg[m + (size_t)(wc + nt * 16 + fk + 4 * r) * ld] = fma(1.0, cv[nt][r], -1.0 * acc[nt][r]);
+                for (int r = 0; r < 4; ++r) Cg[m + (size_t)(wc + nt * 16 + fk + 4 * r) * ldc] = fma(1.0, cv[nt][r], -1.0 * acc[nt][r]);
             return;
         }
 #pragma unroll
@@ -638,7 +650,7 @@ __device__ __noinline__ void mega_gemm_tile(const double *__restrict__ Ap, const
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int n = wc + nt * 16 + fk + 4 * r;
-                cv[nt][r] = (m < n) ? 0.0 : Cg[m + (size_t)n * ld];
+                cv[nt][r] = (m < n) ? 0.0 : Cg[m + (size_t)n * ldc];
             }
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
@@ -646,7 +658,7 @@ __device__ __noinline__ void mega_gemm_tile(const double *__restrict__ Ap, const
             for (int r = 0; r < 4; ++r) {
                 const int n = wc + nt * 16 + fk + 4 * r;
                 const double v = fma(1.0, cv[nt][r], -1.0 * acc[nt][r]);
-                if (!(m < n)) Cg[m + (size_t)n * ld] = v;
+                if (!(m < n)) Cg[m + (size_t)n * ldc] = v;
             }
         return;
     }
@@ -693,12 +705,12 @@ __device__ __noinline__ void mega_gemm_tile(const double *__restrict__ Ap, const
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) cv[r][mt] = Cg[(wm + mt * 16 + fr) + (size_t)(wn + nt * 16 + fk + 4 * r) * ld];
+                for (int mt = 0; mt < 4; ++mt) cv[r][mt] = Cg[(wm + mt * 16 + fr) + (size_t)(wn + nt * 16 + fk + 4 * r) * ldc];
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt)
-                    Cg[(wm + mt * 16 + fr) + (size_t)(wn + nt * 16 + fk + 4 * r) * ld] = fma(1.0, cv[r][mt], -1.0 * acc[nt][mt][r]);
+                    Cg[(wm + mt * 16 + fr) + (size_t)(wn + nt * 16 + fk + 4 * r) * ldc] = fma(1.0, cv[r][mt], -1.0 * acc[nt][mt][r]);
         }
         return;
     }
@@ -711,7 +723,7 @@ __device__ __noinline__ void mega_gemm_tile(const double *__restrict__ Ap, const
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
                 const int m = wm + mt * 16 + fr;
-                cv[r][mt] = (m < n) ? 0.0 : Cg[m + (size_t)n * ld];
+                cv[r][mt] = (m < n) ? 0.0 : Cg[m + (size_t)n * ldc];
             }
         }
 #pragma unroll
@@ -721,7 +733,7 @@ __device__ __noinline__ void mega_gemm_tile(const double *__restrict__ Ap, const
             for (int mt = 0; mt < 4; ++mt) {
                 const int m = wm + mt * 16 + fr;
                 const double v = fma(1.0, cv[r][mt], -1.0 * acc[nt][mt][r]);
-                if (!(m < n)) Cg[m + (size_t)n * ld] = v;
+                if (!(m < n)) Cg[m + (size_t)n * ldc] = v;
             }
         }
     }
@@ -794,7 +806,14 @@ __device__ __noinline__ void mega_potrf_block(double *__restrict__ Akk, int lda,
 // the LDS image the factorisation starts from.  On the chain this is one task and ~20 us where panel solve, hand-over, quarter
 // update and hand-over were ~45.  (Round 3's potrf_link128_kernel did the same as a launch; there the rest of the panel had to wait
 // on a helper stream, here it is just more tasks.)
-__device__ __noinline__ void mega_potrf_link(double *__restrict__ A, int lda, double *__restrict__ dinv, int *info, int base, int *__restrict__ done_aux, int epoch) {
+// The FIRST block of an outer panel is linked the same way (round 4, last change): there the update this task completes is the previous
+// panel's OUTER update of the tile, K = 512 -- its first 384 columns are summed ahead of time by three type-5 quarter tasks into a
+// 128 x 128 scratch tile (acc0; they only need rows that were solved a step earlier), this task starts from that sum instead of from
+// zero and adds the last block column's 128 products: the same sequence of matrix-core accumulations per element as the K = 512
+// quarter tiles it replaces (k ascending from the panel's first column, C - sum at the end), so the factor does not change by a bit,
+// and the chain across a panel boundary is this one task instead of panel solve -> hand-over -> K = 512 quarter -> hand-over -> block.
+__device__ __noinline__ void mega_potrf_link(double *__restrict__ A, int lda, double *__restrict__ dinv, int *info, int base, int *__restrict__ done_aux, int epoch,
+                                             const double *__restrict__ acc0) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double *a = sm;                 // NB x PLS: first the strip X, then the block D
     double *dv = sm + NB * PLS;
@@ -842,6 +861,16 @@ __device__ __noinline__ void mega_potrf_link(double *__restrict__ A, int lda, do
     trsm_chunk<7, PLS>(a, sp, fr, fg, fa, dp, ss);
     (void)ss;
     __syncthreads();
+    // the started sums of this wave's tiles (the L fragments' registers are free now), or zeros
+    double4_t acc_init[5];
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+        const int q = wave + 8 * u;
+        int I = 0, J = 0;
+        if (q < 36) tri_coords(q, I, J);
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) acc_init[u][rr] = (acc0 && q < 36) ? acc0[(16 * I + fr) + (16 * J + fg + 4 * rr) * NB] : 0.0;
+    }
     {   // the solved rows go back in place now: the stores drain while the matrix cores run the tile update
         const int li = lane * 2, lc = wave;
 #pragma unroll 8
@@ -854,7 +883,7 @@ __device__ __noinline__ void mega_potrf_link(double *__restrict__ A, int lda, do
         if (q < 36) {
             int I, J;
             tri_coords(q, I, J);
-            double4_t acc = {0.0, 0.0, 0.0, 0.0};
+            double4_t acc = acc_init[u];
 #pragma unroll 8
             for (int ks = 0; ks < 32; ++ks) {
                 const int k = 4 * ks + fg;
@@ -891,7 +920,7 @@ __device__ __noinline__ void mega_potrf_link(double *__restrict__ A, int lda, do
 __global__ __launch_bounds__(MEGA_THREADS, 1) void chol_mega_kernel(double *__restrict__ A, int lda, double *__restrict__ dinv, int *info,
                                                                  const chol_task *__restrict__ tasks, int ntasks, int *__restrict__ done,
                                                                  int *__restrict__ counter, int epoch, int *__restrict__ err, int mode,
-                                                                 unsigned long long *__restrict__ stamps) {
+                                                                 unsigned long long *__restrict__ stamps, double *__restrict__ sums) {
     __shared__ int s_task;
     const int tid = threadIdx.x;
     // Control flow is kept UNIFORM: the loop runs on a scalar task index, and every lane-0 block sits between two barriers of its own.
@@ -938,10 +967,15 @@ __global__ __launch_bounds__(MEGA_THREADS, 1) void chol_mega_kernel(double *__re
                                dinv + (size_t)tk.k0 * NB * 16, lda);
         } else if (tk.type == 4) {
             if (mode & 1)
-                mega_potrf_link(A + (size_t)tk.k0 * NB * ((size_t)lda + 1), lda, dinv + (size_t)tk.k0 * NB * 16, info, tk.k0 * NB, done + tk.q, epoch);
+                mega_potrf_link(A + (size_t)tk.k0 * NB * ((size_t)lda + 1), lda, dinv + (size_t)tk.k0 * NB * 16, info, tk.k0 * NB, done + tk.q, epoch,
+                                tk.j >= 0 ? sums + (size_t)tk.j * NB * NB : nullptr);
+        } else if (tk.type == 5) {
+            if (mode & 4)
+                mega_gemm_tile(A + (size_t)tk.i * NB + (size_t)tk.k0 * NB * lda, A + (size_t)tk.i * NB + (size_t)tk.k0 * NB * lda,
+                               sums + (size_t)tk.j * NB * NB, lda, NB, tk.kb * NB, false, tk.q + 4);
         } else if (mode & 4)
             mega_gemm_tile(A + (size_t)tk.i * NB + (size_t)tk.k0 * NB * lda, A + (size_t)tk.j * NB + (size_t)tk.k0 * NB * lda,
-                           A + (size_t)tk.i * NB + (size_t)tk.j * NB * lda, lda, tk.kb * NB, tk.i == tk.j, tk.q);
+                           A + (size_t)tk.i * NB + (size_t)tk.j * NB * lda, lda, lda, tk.kb * NB, tk.i == tk.j, tk.q);
         // publish: every wave's stores acknowledged, then ONE lane releases at agent scope, sets the flag -- and claims the next task
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -992,11 +1026,11 @@ void gpk_trsm_panel128(hipStream_t s, double *X, int M, int ldx, const double *L
 }
 // tasks: ntasks x 16 ints (chol_task), done: ntasks ints, counter / err: one int each (counter zeroed by the caller in stream order)
 void gpk_chol_mega(hipStream_t s, int num_cu, double *A, int lda, double *dinv, int *d_info, const int *tasks, int ntasks, int *done, int *counter,
-                   int epoch, int *err, unsigned long long *stamps) {
+                   int epoch, int *err, double *sums, unsigned long long *stamps) {
     const int grid = ntasks < num_cu ? ntasks : num_cu;
     static const int mode = [] { const char *e = getenv("GPCORE_MEGA_MODE"); return e ? atoi(e) : 7; }();   // lab: which task bodies run
     hipLaunchKernelGGL(chol_mega_kernel, dim3(grid), dim3(MEGA_THREADS), MEGA_LDS, s, A, lda, dinv, d_info, reinterpret_cast<const chol_task *>(tasks),
-                       ntasks, done, counter, epoch, err, mode, stamps);
+                       ntasks, done, counter, epoch, err, mode, stamps, sums);
 }
 void gpk_ep_link(hipStream_t s, double *X, int ldx, const double *Lmat, const double *dinv, const double *tvec, double *dots, double *X2,
                  const double *cs2, double *D, int ldd) {

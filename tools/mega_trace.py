@@ -37,7 +37,7 @@ t[~(typ != 3)] = 0.0
 print("n=%d np=%d extra=%d: %d tasks, makespan %.1f us (first claim -> last publish)" % (n, np_, extra, nt, t[:, 3].max()))
 live = typ != 3
 classes = (("POTRF", typ == 0), ("link + POTRF", typ == 4), ("TRSM", typ == 1), ("UPD K=128 full", (typ == 2) & (kb == 1) & (q < 0)), ("UPD K=128 quarter", (typ == 2) & (kb == 1) & (q >= 0)),
-           ("UPD K=512 full", (typ == 2) & (kb > 1) & (q < 0)), ("UPD K=512 quarter", (typ == 2) & (kb > 1) & (q >= 0)))
+           ("UPD K=512 full", (typ == 2) & (kb > 1) & (q < 0)), ("UPD K=512 quarter", (typ == 2) & (kb > 1) & (q >= 0)), ("started sum quarter", typ == 5))
 busy = 0.0
 for name, m in classes:
     if not m.any():
