@@ -546,11 +546,13 @@ constexpr int MEGA_THREADS = 512;
 // tile (128 x 128 at Cp) -= A (128 x K at Ap) B (128 x K at Bp)^T, all with leading dimension ld: gemm_nt_f64_kernel's products (8 waves
 // x 64 x 32, BK = 16) on the workgroup's dynamic LDS.  diag: elements above the diagonal are neither read nor written.  quarter q >= 0:
 // only the 64 x 64 quarter (row half q & 1, column half q >> 1) is computed and stored, by all eight waves.
-// Staging: a RING of four k-slices filled by LDS-DMA three slices ahead.  The launch-per-step kernel gets by with two buffers because
-// two workgroups share a CU; here there is one, two waves per SIMD, and the tasks of 256 workgroups are spread over the matrix with no
-// two neighbours on the same XCD: the operands come from HBM, not L2 (PMC: 12.9 GB per factorisation, 24 x the matrix,
-// profiles/r04_final pmc_c2 first pass), and with the next slice requested only one slice ahead every k step waited for memory --
-// 2.46 us per step against 1.7 us of matrix-core time, a quarter (0.2 us of matrix-core time per step) 0.9 us.
+// Staging: two buffers of 32 k-columns each, filled by LDS-DMA one slice ahead, one barrier per slice.  (One workgroup per CU, two waves
+// per SIMD, and the tasks of 256 workgroups spread over the matrix with no two neighbours on one XCD: the operands come from HBM, not
+// L2 -- PMC: 12.9 GB per factorisation, 24 x the matrix.  All the same the loop does not wait for memory: a ring of four 16-column slices
+// with the DMA three slices ahead measured the same 77-80 us per K = 512 tile as two buffers one slice ahead
+// (profiles/r04_o_fit_mega_ring_only.log), slices of 32 instead of 16 -- half the barriers -- 76.2 against 77.8 us
+// (profiles/r04_t_mega_trace_kslice32.log): the tile runs at ~0.85 of the matrix pipe's rate at the clock the chip holds, the
+// launch-per-step kernel gets its last 10 % from the second workgroup on the CU.)
 // quarter q + 4: the quarter's sum of products alone, written (all 64 x 64 elements, nothing read) to Cp with leading dimension ldc --
 // a STARTED sum that mega_potrf_link continues (the first block of an outer panel, below).
 __device__ __noinline__ void mega_gemm_tile(const double *__restrict__ Ap, const double *__restrict__ Bp, double *__restrict__ Cp,
@@ -571,13 +573,13 @@ __device__ __noinline__ void mega_gemm_tile(const double *__restrict__ Ap, const
     diag = __builtin_amdgcn_readfirstlane((int)diag) != 0;
     typedef __attribute__((address_space(1))) double gdouble;
     gdouble *const Cg = (gdouble *)Cp;
-    constexpr int TKm = 16, STR = 144, NST = 4;
-    double *As = sm, *Bs = sm + NST * TKm * STR;
+    constexpr int TKm = 32, STR = 144;      // 2 buffers x 2 operands x 32 x 144 doubles = 144 KB
+    double *As = sm, *Bs = sm + 2 * TKm * STR;
     const int lane = tid & 63, wave = tid >> 6, fr = lane & 15, fk = lane >> 4;
     const double *Asrc = Ap + lane * 2 + (size_t)wave * ld, *Bsrc = Bp + lane * 2 + (size_t)wave * ld;
-    auto stage = [&](int kt) {      // k-slice kt into ring slot kt % NST: four LDS-DMA instructions per wave
+    auto stage = [&](int kt) {      // k-slice kt into buffer kt & 1: eight LDS-DMA instructions per wave
         const size_t koff = (size_t)kt * TKm;
-        const int buf = kt & (NST - 1);
+        const int buf = kt & 1;
 #pragma unroll
         for (int q = 0; q < TKm / 8; ++q) {
             __builtin_amdgcn_global_load_lds(Asrc + (koff + 8 * q) * ld, As + (buf * TKm + wave + 8 * q) * STR, 16, 0, 0);
@@ -585,19 +587,15 @@ __device__ __noinline__ void mega_gemm_tile(const double *__restrict__ Ap, const
         }
     };
     const int KT = K / TKm;
-    // slice kt is in LDS for everybody: this wave's own share has landed (the two slices requested after it may still be in flight:
-    // vmcnt counts in issue order), its reads of the slice before are done, then the barrier; the slot of slice kt - 1 is free after it
+    // slice kt is in LDS for everybody: this wave's own share has landed and its reads of the slice before are done, then the barrier;
+    // the other buffer is free after it and takes slice kt + 1 while the matrix cores run slice kt
     auto arrive = [&](int kt) {
-        if (kt + 2 < KT) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-        else if (kt + 1 < KT) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (kt + 3 < KT) stage(kt + 3);
+        if (kt + 1 < KT) stage(kt + 1);
     };
     stage(0);
-    if (KT > 1) stage(1);
-    if (KT > 2) stage(2);
     if (quarter >= 0) {
         // A quarter is on the chain's way (the next diagonal block's tile): all eight waves share its 64 x 64 -- wave w: rows 16 (w & 3),
         // columns 32 (w >> 2), two accumulators -- so its k loop is a quarter of a full tile's instead of the same length on two waves.
@@ -606,7 +604,7 @@ __device__ __noinline__ void mega_gemm_tile(const double *__restrict__ Ap, const
         double4_t acc[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
         for (int kt = 0; kt < KT; ++kt) {
             arrive(kt);
-            const int cur = kt & (NST - 1);
+            const int cur = kt & 1;
             const double *Ac = As + cur * TKm * STR + wr + fr, *Bc = Bs + cur * TKm * STR + wc + fr;
             // fragments one k-group ahead of the matrix cores (two waves per SIMD, in step with each other: nothing else hides an LDS read)
             double af = Ac[fk * STR], bf0 = Bc[fk * STR], bf1 = Bc[fk * STR + 16];
@@ -670,7 +668,7 @@ __device__ __noinline__ void mega_gemm_tile(const double *__restrict__ Ap, const
         for (int b = 0; b < 4; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
     for (int kt = 0; kt < KT; ++kt) {
         arrive(kt);
-        const int cur = kt & (NST - 1);
+        const int cur = kt & 1;
         const double *Ac = As + cur * TKm * STR + wm + fr, *Bc = Bs + cur * TKm * STR + wn + fr;
         double afn[4], bfn[2];
 #pragma unroll
@@ -999,7 +997,7 @@ static constexpr int POTRF_LDS = (NB * PLS + 256 + 8) * (int)sizeof(double);
 static constexpr int TRSM_LDS = NB * XS * (int)sizeof(double);
 static constexpr int STEP_LDS = (NB * LS1 + 8 * 256 + NB + 16) * (int)sizeof(double);
 static constexpr int LINK_LDS = NB * LKS * (int)sizeof(double);
-static constexpr int MEGA_LDS = POTRF_LDS > LINK_LDS ? POTRF_LDS : LINK_LDS;     // the diagonal block's image / the 128-row strip / 144 KB of GEMM staging (ring of four k-slices)
+static constexpr int MEGA_LDS = POTRF_LDS > LINK_LDS ? POTRF_LDS : LINK_LDS;     // the diagonal block's image / the 128-row strip / 144 KB of GEMM staging (two buffers of 32 k-columns)
 
 int gpk_init_diag_kernels() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(potrf_diag128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, POTRF_LDS);
