@@ -72,6 +72,13 @@ def test_single_launch_cholesky_plan_is_a_valid_schedule():
         nb, nrow = n // 128, (n + extra) // 128
         assert nt.value >= nb + sum(nrow - k - 1 for k in range(nb)) and us.value > 0.0
         seen[(n, extra, wg)] = (nt.value, us.value)
+    # every shape the library may plan: all row-block counts from one outer panel to past the C2 size's, ragged last panels, with and
+    # without the extra row block, few and many workgroups (the replay inside gp_chol_plan_info is the check)
+    for nb in list(range(1, 42)) + [47, 53, 64, 65, 79, 96, 112]:
+        for extra in (0, 128):
+            for wg in (256, 3) if nb in (5, 17, 41, 64) else (256,):
+                assert lib.gp_chol_plan_info(128 * nb, extra, wg, C.byref(nt), C.byref(us)) == L.GP_OK, (nb, extra, wg)
+                assert nt.value > 0 and us.value > 0.0
     assert seen[(8192, 0, 64)][1] > seen[(8192, 128, 256)][1]                    # a quarter of the workgroups: a longer schedule
     assert 3000.0 < seen[(8192, 128, 256)][1] < 5000.0                           # the model's n = 8192: about 4 ms on 256 CUs
     for bad in ((100, 0, 256), (8192, 64, 256), (8192, 256, 256), (8192, 0, 0)):

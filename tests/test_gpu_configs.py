@@ -286,6 +286,33 @@ def test_cholesky_default_is_the_single_launch_where_it_wins(ctx, monkeypatch):
         assert np.array_equal(factors[(n, None)], factors[(n, "0")])
 
 
+def test_cholesky_single_launch_state_is_per_context_and_per_shape(ctx, monkeypatch):
+    """The single launch keeps its plan, flags and claim counter in the context: two contexts refitting models of different sizes in
+    turn, with nothing but stream order between the launches of each, and one context going back and forth between two shapes (the
+    plan is rebuilt, the flags' epoch goes on) must each give the factor the launch-per-step form gives."""
+    from gp_algos_amd import _lib as L
+    from gp_algos_amd.core import Context, RegressionModel
+    other = Context(0)
+    try:
+        probs = {n: synth.regression(n, 3, 0, 70 + n % 7, 71, 0, np.array([1.1, 0.8, 1.2, 0.9, 0.25])) for n in (5200, 6400)}
+        monkeypatch.setenv("GPCORE_CHOL_MEGA", "0")
+        want = {}
+        for n, p in probs.items():
+            m = RegressionModel(ctx, p["X"], p["y"], p["theta"])
+            want[n] = (m.L(), m.alpha())
+            m.close()
+        monkeypatch.setenv("GPCORE_CHOL_MEGA", "1")
+        models = {(c, n): RegressionModel(c, probs[n]["X"], probs[n]["y"], probs[n]["theta"]) for c in (ctx, other) for n in probs}
+        for _ in range(3):                                   # interleaved: ctx 5200, other 6400, ctx 6400, other 5200, ...
+            for (c, n), m in models.items():
+                c.check(c._lib.gp_model_refit_dev(m.h, L.dptr(L.f64(probs[n]["theta"])), float("nan")))
+        for (c, n), m in models.items():
+            assert np.array_equal(m.L(), want[n][0]) and np.array_equal(m.alpha(), want[n][1]), n
+            m.close()
+    finally:
+        other.close()
+
+
 def test_cholesky_lookahead_on_the_side_stream_is_the_same_factorisation(ctx):
     """The far trailing updates on the CU-masked side stream (default for single factorisations with >= 6144 rows, i.e. the C2 fit)
     against the one-stream form: the same tiles by the same kernels, so L, alpha and the LML must be IDENTICAL -- also when
