@@ -37,7 +37,7 @@ struct ws_slot { void *p = nullptr; size_t bytes = 0; unsigned long long tag = 0
 struct mega_task { int type, k0, kb, i, j, q, dep[10]; };
 struct mega_plan { int np = 0, extra = 0, out_blocks = 0, workers = 0; double model_us = 0.0; std::vector<mega_task> tasks; };
 // the persistent-launch factorisation's state: the plan of the shape used last, its copy on the device, the flags
-struct mega_state { mega_plan plan; int *d_tasks = nullptr, *d_done = nullptr, *d_ctl = nullptr; double *d_sums = nullptr; int cap = 0, epoch = 0, sums_cap = 0; };
+struct mega_state { mega_plan plan; int *d_tasks = nullptr, *d_done = nullptr, *d_ctl = nullptr; double *d_sums = nullptr; int cap = 0, epoch = 0, sums_cap = 0, seen_np = 0, seen_extra = -1; };
 
 struct ctx_ext { ws_slot ws[WS_COUNT]; std::vector<gp_ctx *> children; mega_state mega; };
 
@@ -326,10 +326,17 @@ bool chol_mega_plan(int np, int extra, int out_blocks, int workers, mega_plan &p
 
 // Runs the factorisation as one persistent launch on the context's stream; false = not available (allocation, planning): the caller
 // falls back to the launch-per-step form.  d_ctl: [0] the claim counter (zeroed in stream order before every launch), [1] the error word.
-bool chol_mega_run(gp_ctx *ctx, double *A, int np, int lda, double *dinv, int extra, int out_blocks) {
+// A plan costs host time once per shape (list schedule of the whole DAG: 4 / 13 / 68 ms at n = 5120 / 8192 / 14336) and the context keeps
+// ONE: a shape is planned when it comes the second time in a row (the first factorisation of a shape, and shapes that alternate,
+// take the launch-per-step form, which is 1 ms slower, not 13); GPCORE_CHOL_MEGA=1 plans at once.
+bool chol_mega_run(gp_ctx *ctx, double *A, int np, int lda, double *dinv, int extra, int out_blocks, bool plan_at_once) {
     mega_state &ms = ext_of(ctx)->mega;
     const int workers = ctx->num_cu;
     if (ms.plan.np != np || ms.plan.extra != extra || ms.plan.out_blocks != out_blocks || ms.plan.workers != workers) {
+        if (!plan_at_once && !(ms.seen_np == np && ms.seen_extra == extra)) {
+            ms.seen_np = np, ms.seen_extra = extra;
+            return false;
+        }
         mega_plan pl;
         if (!chol_mega_plan(np, extra, out_blocks, workers, pl)) return false;
         const int n = (int)pl.tasks.size();
@@ -417,7 +424,7 @@ void chol_blocked(gp_ctx *ctx, double *A, int np, int lda, double *dinv, int ext
         const bool forced = me && atoi(me) != 0, off = me && atoi(me) == 0;
         const bool by_size = np >= 5120 && np <= 14336;
         if (!off && (forced || by_size) && lookahead && info == ctx->d_info && np >= 4 * OUTER && extra <= GP_NB &&
-            chol_mega_run(ctx, A, np, lda, dinv, extra, OUTER / GP_NB)) return;
+            chol_mega_run(ctx, A, np, lda, dinv, extra, OUTER / GP_NB, forced)) return;
     }
     // (Round 4 tried the chain on the outer panel's OWN rows only, with the rows under the panel -- panel solve and their share of the
     // in-panel update -- on a second stream gated by one event per step: bit-identical, and slower at every size (n = 8192 refit 6.86

@@ -255,14 +255,16 @@ def test_cholesky_single_launch_and_lookahead_forms_agree_with_the_first_bad_piv
         ctx.check(lib.gp_ctx_set_lookahead(ctx.h, -1))
 
 
-def test_cholesky_default_is_the_single_launch_where_it_wins(ctx, monkeypatch):
-    """Which form runs is a size rule inside the library (5120 <= rows <= 14336: profiles/r04_final_fit_mega.log); the library's
-    own launch counters say which one did: the single persistent launch is ONE launch of the trailing-update class per refit, the
-    launch-per-step form one per outer panel and more.  Same factor either way."""
+def test_cholesky_default_is_the_single_launch_where_it_wins(monkeypatch):
+    """Which form runs is a size rule inside the library (5120 <= rows <= 14336: profiles/r04_final_fit_mega.log) plus one condition:
+    a shape is planned when it comes the second time in a row (the plan costs 4-68 ms of host time, a one-off factorisation is better
+    off without it).  The library's own launch counters say which form ran: the single persistent launch is ONE launch of the
+    trailing-update class per refit, the launch-per-step form one per outer panel and more.  Same factor either way."""
     from gp_algos_amd import _lib as L
-    from gp_algos_amd.core import RegressionModel
+    from gp_algos_amd.core import Context, RegressionModel
+    ctx = Context(0)                # its own context: what a context has planned before is part of the rule
     lib = ctx._lib
-    launches, factors = {}, {}
+    launches, factors, first = {}, {}, {}
     for n in (6400, 4608):
         p = synth.regression(n, 4, 0, 61, 62, 0, np.array([1.2, 0.9, 1.3, 0.7, 1.1, 0.2]))
         for mega in (None, "0"):
@@ -270,20 +272,23 @@ def test_cholesky_default_is_the_single_launch_where_it_wins(ctx, monkeypatch):
                 monkeypatch.delenv("GPCORE_CHOL_MEGA", raising=False)
             else:
                 monkeypatch.setenv("GPCORE_CHOL_MEGA", mega)
-            m = RegressionModel(ctx, p["X"], p["y"], p["theta"])
-            ctx.sync()
             ctx.profile_read(L.GP_PROF_SYRK)                      # (reading resets the class's counters)
             ctx.profile(1 << L.GP_PROF_SYRK)
+            m = RegressionModel(ctx, p["X"], p["y"], p["theta"])  # the shape's first factorisation: launch-per-step in every case
+            ctx.sync()
+            first[(n, mega)] = ctx.profile_read(L.GP_PROF_SYRK)[0]
             ctx.check(lib.gp_model_refit_dev(m.h, L.dptr(L.f64(p["theta"])), float("nan")))
             ctx.sync()
             launches[(n, mega)] = ctx.profile_read(L.GP_PROF_SYRK)[0]
             ctx.profile(0)
             factors[(n, mega)] = m.L()
             m.close()
+    assert first[(6400, None)] == first[(6400, "0")] > 5                    # the first factorisation of a shape: never planned
     assert launches[(6400, None)] == 1 and launches[(6400, "0")] > 5        # by default one launch at 6400 rows ...
     assert launches[(4608, None)] == launches[(4608, "0")] > 5              # ... and the launch-per-step form below 5120
     for n in (6400, 4608):
         assert np.array_equal(factors[(n, None)], factors[(n, "0")])
+    ctx.close()
 
 
 def test_cholesky_single_launch_state_is_per_context_and_per_shape(ctx, monkeypatch):
