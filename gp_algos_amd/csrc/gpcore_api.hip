@@ -141,14 +141,15 @@ void gemm_sub_single(hipStream_t s, int M, int N, int K, const double *A, int ld
 // ---- the factorisation of ONE matrix as one persistent launch (chol_mega_kernel, kernels_diag.hip) ----
 // Task list of the two-level right-looking factorisation (inner 128, outer panels of `out_blocks` block columns), in a LIST-SCHEDULE
 // order: the tasks are generated in the order chol_blocked launches them, a critical-path-first schedule of that DAG on `workers`
-// workgroups is simulated with a cost model (us per task on one CU, measured with tools/mega_trace.py: diagonal block 25, 128-row panel
-// solve 22, 128 x 128 tile with K = 128 / 512: 28 / 81, a 64 x 64 quarter 9 / 20, a hand-over between workgroups 3), and the list is the tasks in the
-// order the simulation starts them.  Workgroups claim tasks in list order, so on the chip the dependencies of a claimed task are
-// mostly met already and the chain (diagonal block with its link to the block before; at a panel boundary: solve of the next block's rows -> the quarters of the next diagonal tile) is
-// never waiting behind throughput work.  Every dependency points BACKWARDS in the list (checked): no deadlock.
-// What the static order leaves on the table, and what did not recover it (round 4, n = 8192 refit 4.9 ms with this list; the traces are
-// tools/mega_trace.py's, the variants are kept as tools/lab/mega_claim_ahead.patch):
-//   - the mean step from one diagonal block to the next is ~77 us against ~55 of task bodies: in some phases of the factorisation the
+// workgroups is simulated with a cost model (us per task on one CU, measured with tools/mega_trace.py: the constants below; a hand-over
+// between workgroups 3), and the list is the tasks in the order the simulation starts them.  Workgroups claim tasks in list order, so
+// on the chip the dependencies of a claimed task are mostly met already.  Every dependency points BACKWARDS in the list (checked):
+// no deadlock.  The model is accurate -- with the measured task costs its makespan at n = 8192 is 4.79 ms against 4.7-4.85 measured --
+// so it also answers what-ifs without a GPU (gp_chol_plan_info with GPCORE_MEGA_COSTS): K = 512 tile at 65 instead of 77.7 us 4.33 ms,
+// the link at half its time 4.71 ms, tiles for free 3.86 ms.
+// What the static order leaves on the table, and what did not recover it (round 4; the traces are tools/mega_trace.py's, the scheduling
+// variants are kept as tools/lab/mega_claim_ahead.patch):
+//   - the mean step from one diagonal block to the next is ~75 us against ~57 of task bodies: in some phases of the factorisation the
 //     chip is behind the model and the chain's tasks are claimed 10-60 us after their dependencies were met, in others it is ahead and
 //     they are claimed up to 400 us early (profiles/r04_i_mega_chain_detail.log);
 //   - the chain's tasks a fixed lead (0..200 us of model time) earlier in the list: 4.99-5.09 ms, the lag is not a constant
@@ -159,8 +160,12 @@ void gemm_sub_single(hipStream_t s, int M, int N, int K, const double *A, int ld
 //   - that queue claimed a bounded number of tasks AHEAD (4..64 outstanding) by workgroups that then wait: 5.27-6.03 ms, every
 //     outstanding task is a CU spinning and the late dependencies are one level further out, in the bulk (profiles/r04_l_*, r04_m_*:
 //     with every in-panel task of the next 2 / 4 / 8 block rows in the chain queue 5.47 / 5.53 / 5.65 ms);
-//   - block k's link given an early phase (the previous panel's earlier block columns applied before block k-1's factor arrives) and
-//     the first block of every panel fused the same way: 4.92-5.10 ms, no better (profiles/r04_i_fit_mega_lead_order.log is that variant).
+//   - every block's link given an early phase INSIDE its task (the previous panel's earlier block columns applied before block k-1's
+//     factor arrives): 4.92-5.10 ms, no better (profiles/r04_i_fit_mega_lead_order.log).  What is kept instead is that early part as
+//     tasks of their own (type 5, below): the gap across a panel boundary fell from 85 to 15 us, the gaps inside panels rose from 8 to
+//     18 us, the mean step stayed -- 2-7 % at n = 5120 ... 14336 (profiles/r04_q_*);
+//   - pairs of tiles as 256 x 128 tasks: in the model 5.35 ms at n = 8192 (coarser tasks stand in the chain's way), 4.69 when only
+//     columns a panel or more to the right are paired; not built.
 bool chol_mega_plan(int np, int extra, int out_blocks, int workers, mega_plan &plan) {
     const int nb = np / GP_NB, nrow = (np + extra) / GP_NB;
     struct node { mega_task t; double cost; std::vector<int> deps; };

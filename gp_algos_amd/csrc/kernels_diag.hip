@@ -525,8 +525,10 @@ __global__ __launch_bounds__(64) void tile_inverse_kernel(const double *__restri
 // update's workgroups (2-4x slower), and late in the factorisation the chip idles through every diagonal block.
 // Here one workgroup per CU (512 threads, the diagonal-block kernel's 150 KB of LDS) takes tasks off a list, in list order, until the
 // list is empty:
-//   POTRF(k)            the diagonal block (potrf_block_body, as potrf_diag128_kernel); inside an outer panel with its link to the block
-//                       before as the prologue (mega_potrf_link: the solve of its own rows and its last in-panel update, fused);
+//   POTRF(k)            the diagonal block (potrf_block_body, as potrf_diag128_kernel); every block but the first with its link to the
+//                       block before as the prologue (mega_potrf_link: the solve of its own rows and the update of its tile that those
+//                       rows complete -- the in-panel one, or, for a panel's first block, the previous panel's outer one, whose earlier
+//                       columns three SUM tasks have added up ahead of time in a scratch tile);
 //   TRSM(k, i)          row block i of block column k:  X <- X L_kk^-T  (128 rows: the strip solve of trsm_panel128 / ep_link);
 //   UPD(k0, kb, i, j)   tile (i, j) -= X[i, k0..k0+kb) X[j, k0..k0+kb)^T  with K = 128 kb: the in-panel updates (kb = 1) and the outer
 //                       updates (kb = 4) of the two-level scheme -- the SAME products in the SAME order per element as the launches of
